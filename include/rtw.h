@@ -1,0 +1,225 @@
+/*
+ * rtw.h -- C ABI of the MI355X-native path tracer (librtw_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Terence-23/RayTracing-in-a-weekend:
+ *
+ *     Viewport::render / render_row  ->  ray_color_*  ->  Sphere::collision_normal  ->  Material::on_hit
+ *
+ * The reference has no FFI: its seam is the function-typed `ray_color` parameter of
+ *   Rust/src/viewport.rs:430      Viewport::render(&self, ray_color: &dyn Fn(Ray,&Scene,usize)->Rgb<f32>, scene)
+ *   Rust/src/viewport.rs:215-219  async_render(viewport: Box<Viewport>, ray_color, scene: Box<Scene>) -> Img
+ *   Rust2/src/viewport.rs:116,128 Viewport::render_rows_async(self) / render(self)
+ *   C++/headers/viewport.h:95     Img Viewport::Render(RGB_float (*ray_color)(...), const Scene&)
+ * A host closure cannot cross to the GPU, so the integrator is selected by enum and the scene is
+ * passed as flat PODs.  Everything here is plain C: pointers, sizes, PODs; no torch, no C++ types.
+ *
+ * Conventions
+ *   - caller owns every buffer; the library allocates only device scratch inside an rtw_ctx
+ *   - no exceptions / panics cross the ABI: 0 == RTW_OK, negative == RTW_E_*
+ *   - rtw_ctx_render() is blocking (mirrors `rt.block_on(render_multi(..))`, Rust/src/main.rs:76-78)
+ *   - one rtw_ctx == one GPU == one HIP stream; contexts are independent (one per process/rank)
+ *   - all arithmetic is f32 (Rust/src/vec3.rs:11-15)
+ */
+#ifndef RTW_H
+#define RTW_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTW_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define RTW_OK              0
+#define RTW_E_INVALID      -1   /* bad argument (NULL pointer, zero size, unknown enum value)        */
+#define RTW_E_NO_DEVICE    -2   /* no HIP device / device index out of range                         */
+#define RTW_E_HIP          -3   /* a HIP runtime call failed (rtw_last_hip_error() has the code)     */
+#define RTW_E_NOMEM        -4   /* host or device allocation failed                                  */
+#define RTW_E_UNSUPPORTED  -5   /* valid enum value that this build does not implement on the device */
+#define RTW_E_NO_SCENE     -6   /* rtw_ctx_render() before rtw_ctx_set_scene()                       */
+
+/* ---- integrators: which `ray_color` closure the reference would have passed ----------------- */
+enum {
+    RTW_INTEGRATOR_GRADIENT = 0, /* ray_color_gradient, Rust/src/viewport/ray_color.rs:12-41 (== ray_color_d main.rs:17-46) */
+    RTW_INTEGRATOR_BG_COLOR = 1, /* ray_color_bg_color, Rust/src/viewport/ray_color.rs:43-92 (emission + background)        */
+    RTW_INTEGRATOR_NORMAL   = 2, /* normal shading of the closest hit, C++/src/tests.cpp:76-97 (ray_colorSc)                */
+    RTW_INTEGRATOR_FLAG     = 3  /* RNG-free yellow/blue test integrator, Rust/src/viewport/glass_tests.rs:8-54             */
+};
+
+/* ---- samplers: which driver loop generates the camera rays ---------------------------------- */
+enum {
+    RTW_SAMPLER_ROW        = 0, /* render_row: exactly `samples` unstratified, shutter time; Rust/src/viewport.rs:270-305 */
+    RTW_SAMPLER_STRATIFIED = 1, /* Viewport::render: ceil(sqrt(samples))^2 strata, time 0; Rust/src/viewport.rs:430-478   */
+    RTW_SAMPLER_CENTRES    = 2, /* Rust2 render_row: floor(sqrt(samples))^2 fixed centres; Rust2/src/viewport.rs:87-114   */
+    RTW_SAMPLER_NO_RAND    = 3  /* render_no_rand: one un-jittered ray per pixel; Rust/src/viewport.rs:479-516            */
+};
+
+/* ---- closest-hit strategy (result-invariant) ------------------------------------------------ */
+enum {
+    RTW_ACCEL_BRUTE = 0, /* every sphere, list order (the reference's test integrators: camera_tests.rs:19-33)   */
+    RTW_ACCEL_BVH   = 1  /* device BVH, time-expanded bounds (Scene::collision_normal -> AABB, viewport.rs:136-150) */
+};
+
+/* ---- PODs ----------------------------------------------------------------------------------- */
+
+/* The render-time fields of `Viewport` (Rust/src/viewport.rs:49-77), produced by
+ * rtw_viewport_new() == Viewport::new (viewport.rs:308-401).  `pixel00` is
+ * `upper_left_corner`: a DIRECTION (the origin is not added, viewport.rs:377-378). */
+typedef struct RtwCamera {
+    float origin[3];
+    float u[3];
+    float v[3];
+    float pixel00[3];
+    float delta_u[3];     /* p_delta_u */
+    float delta_v[3];     /* p_delta_v */
+    float lens_radius;
+    float time0;          /* frame as f32 / fps            (viewport.rs:279) */
+    float shutter;        /* shutter_speed                 (viewport.rs:297) */
+} RtwCamera;
+
+/* `Sphere` (Rust/src/objects/sphere.rs:13-20) with its `Material` (materials.rs:15-20) inlined.
+ * `tex < 0` means the sphere carries the 1x1 ImageTexture::from_color(tex_color) that
+ * Sphere::new builds (sphere.rs:151-173); the albedo the hit reports is texel * col_mod
+ * (sphere.rs:145), so Sphere::new(c) yields c*c -- that quirk is reproduced by passing
+ * tex_color == col_mod == c. */
+typedef struct RtwSphere {
+    float center[3];      /* origin                                   */
+    float radius;
+    float velocity[3];    /* centre(t) = origin + velocity * ray.time  (sphere.rs:100) */
+    float col_mod[3];
+    float tex_color[3];
+    float metallicness;
+    float opacity;        /* > 0 selects the dielectric branch (materials.rs:106) */
+    float ir;
+    float emitted[3];     /* `emmited` */
+    int32_t tex;          /* index into RtwScene.textures, or -1 */
+} RtwSphere;
+
+/* `ImageTexture{img,row,col}` (Rust/src/texture.rs:21-27): row == width, col == height,
+ * texel (x,y) lives at texels[3*(texel_offset + y*row + x)] (texture.rs:265). Perlin noise is
+ * out of scope. */
+typedef struct RtwTexture {
+    uint32_t row;
+    uint32_t col;
+    uint32_t texel_offset;
+    uint32_t reserved;
+} RtwTexture;
+
+/* `Scene` restricted to spheres (Rust/src/viewport.rs:79-151). */
+typedef struct RtwScene {
+    const RtwSphere  *spheres;
+    const RtwTexture *textures;   /* may be NULL when n_textures == 0 */
+    const float      *texels;     /* [n_texels][3], may be NULL       */
+    uint32_t n_spheres;
+    uint32_t n_textures;
+    uint32_t n_texels;
+    float    background[3];       /* Scene.background_color (BG_COLOR integrator only) */
+} RtwScene;
+
+typedef struct RtwParams {
+    uint32_t width, height;       /* full image */
+    uint32_t samples;             /* Viewport.samples (see sampler for the count actually traced) */
+    uint32_t depth;               /* Viewport.depth: max closest-hit queries per camera ray       */
+    float    gamma;               /* output = powf(mean, 1/gamma) (viewport.rs:207-213)           */
+    float    mint, maxt;          /* 0.001 / 1e5 in ray_color_gradient, 1e4 bg_color, 1e3 ray_color_d */
+    uint32_t integrator;          /* RTW_INTEGRATOR_* */
+    uint32_t sampler;             /* RTW_SAMPLER_*    */
+    uint32_t accel;               /* RTW_ACCEL_*      */
+    uint32_t flags;               /* RTW_FLAG_*       */
+    uint64_t seed;                /* render seed of the counter-based RNG (DESIGN.md "RNG") */
+    /* Row partition for multi-GPU: this call renders the rows r with
+     *   (r / row_block) % part_count == part_index,
+     * written compactly in increasing r to out_rgb[rows][width][3].
+     * part_count <= 1 renders every row. */
+    uint32_t row_block;
+    uint32_t part_index;
+    uint32_t part_count;
+    uint32_t reserved;
+} RtwParams;
+
+#define RTW_FLAG_NONE            0u
+#define RTW_FLAG_RECURSIVE_ORDER 1u  /* oracle only: multiply col_mod in the reference's recursion order */
+
+typedef struct RtwStats {
+    uint64_t camera_rays;    /* (pixel, sample) primary rays traced                   */
+    uint64_t segments;       /* closest-hit queries == BASELINE "rays x bounces"      */
+    uint64_t sphere_tests;   /* exact ray/sphere quadratic evaluations                */
+    uint64_t node_tests;     /* BVH node slab tests (0 for RTW_ACCEL_BRUTE)           */
+    uint32_t nan_pixels;     /* output pixels with a NaN channel                      */
+    uint32_t rows;           /* rows written by this call                             */
+    float    kernel_ms;      /* device time of the render kernels (hipEvent)          */
+    float    total_ms;       /* host wall time of the call                            */
+} RtwStats;
+
+typedef struct rtw_ctx rtw_ctx;
+
+/* ---- device path (librtw_hip.so) ------------------------------------------------------------ */
+
+int         rtw_abi_version(void);
+int         rtw_device_count(void);
+const char *rtw_strerror(int status);
+int         rtw_last_hip_error(void);
+
+/* One context per GPU.  `device` is the HIP device ordinal. */
+int  rtw_ctx_create(int device, rtw_ctx **out);
+void rtw_ctx_destroy(rtw_ctx *ctx);
+/* Launch on this HIP stream (a hipStream_t passed as void*), NULL = the context's own stream. */
+int  rtw_ctx_set_stream(rtw_ctx *ctx, void *hip_stream);
+/* == Scene::new_sphere(spheres) (viewport.rs:90-105): copies the scene to the GPU and builds the
+ * acceleration structure.  [t_begin, t_end] is the ray.time range the bounds must cover
+ * (time0 .. time0 + shutter); pass 0,0 for static scenes. */
+int  rtw_ctx_set_scene(rtw_ctx *ctx, const RtwScene *scene, float t_begin, float t_end);
+/* == Viewport::render(ray_color, scene) -> Img.  out_rgb is [rows][width][3] f32, gamma-corrected,
+ * unclamped (viewport.rs:301); it may be host memory or device memory of ctx's GPU. */
+int  rtw_ctx_render(rtw_ctx *ctx, const RtwCamera *cam, const RtwParams *params,
+                    float *out_rgb, RtwStats *stats);
+/* One-shot convenience: create ctx on the current device, set scene, render, destroy. */
+int  rtw_render(const RtwCamera *cam, const RtwScene *scene, const RtwParams *params,
+                float *out_rgb, RtwStats *stats);
+
+/* ---- host mirror of the reference constructors (same library, no GPU needed) ---------------- */
+
+/* Viewport::new (viewport.rs:308-401).  Options the reference takes as Option<> are pointers
+ * (NULL == None).  Writes the camera and the derived height `(width as f32 / aspect) as u64`. */
+int rtw_viewport_new(uint32_t width, float aspect_ratio, const float *vfov, const float *origin,
+                     const float *direction, const float *vup, const float *lens_radius,
+                     RtwCamera *cam, uint32_t *height);
+/* Viewport::new_from_res (viewport.rs:402-428): aspect = width as f32 / height as f32. */
+int rtw_viewport_new_from_res(uint32_t width, uint32_t height, const float *vfov, const float *origin,
+                              const float *direction, const float *vup, const float *lens_radius,
+                              RtwCamera *cam, uint32_t *height_out);
+/* Sphere::new / new_moving (sphere.rs:151-199): col_mod==NULL -> (1,1,1); mat==NULL -> EMPTY_M. */
+int rtw_sphere_new(const float origin[3], float radius, const float *col_mod,
+                   const float *mat3 /* metallicness, opacity, ir */, const float *velocity,
+                   RtwSphere *out);
+/* Sphere::new_with_texture (sphere.rs:200-224). */
+int rtw_sphere_new_with_texture(const float origin[3], float radius, const float *col_mod,
+                                const float *mat3, const float *velocity, int32_t tex, RtwSphere *out);
+/* Rows a partition owns (see RtwParams). */
+uint32_t rtw_part_rows(uint32_t height, uint32_t row_block, uint32_t part_index, uint32_t part_count);
+/* write_img_f32 quantisation: round(clamp(c*255, 0, 255)) (Rust/src/write_img.rs:11-15). */
+void rtw_quantize_u8(const float *rgb, size_t n_values, uint8_t *out);
+
+/* Scene generators for the BASELINE configs.  Each fills caller arrays; call with
+ * spheres == NULL to query the counts.  Returns RTW_OK or RTW_E_INVALID if capacity is too small. */
+enum {
+    RTW_SCENE_C1_THREE_SPHERES = 1, /* ground + lambert + metal (material_tests.rs:105-167 trimmed) */
+    RTW_SCENE_C2_BOOK1_FINAL   = 2, /* Book-1 final random spheres, ~485                          */
+    RTW_SCENE_C4_DIELECTRIC    = 4, /* 9x9 hollow-glass grid + fuzzy metal                         */
+    RTW_SCENE_C5_MOTION_CHECKER= 5, /* C2 with moving lambert spheres + 4x2 image-textured ground  */
+    RTW_SCENE_METAL_TEST       = 6  /* 4-sphere metal_test (material_tests.rs:105-167)             */
+};
+int rtw_scene_generate(uint32_t which, uint64_t scene_seed,
+                       RtwSphere *spheres, uint32_t sphere_cap, uint32_t *n_spheres,
+                       RtwTexture *textures, uint32_t texture_cap, uint32_t *n_textures,
+                       float *texels, uint32_t texel_cap, uint32_t *n_texels);
+/* The camera + params each config is quoted with (width/height/samples/depth/lens/vfov/shutter). */
+int rtw_scene_default_view(uint32_t which, RtwCamera *cam, RtwParams *params);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTW_H */

@@ -1,0 +1,60 @@
+/*
+ * rtw_oracle.h -- ABI of the CPU oracle (oracle/librtw_oracle.so).
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library.  The product path (librtw_hip.so) never links,
+ * loads or calls it, and has no CPU fallback.
+ *
+ * The oracle is a plain-C, f32, no-FMA restatement of the reference's hot path
+ * (Rust/src/viewport.rs, viewport/ray_color.rs, objects/sphere.rs, objects/materials.rs, vec3.rs);
+ * see oracle/rtw_oracle.c for the per-function file:line citations.
+ */
+#ifndef RTW_ORACLE_H
+#define RTW_ORACLE_H
+
+#include "rtw.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same contract as rtw_ctx_render(); `threads` row-parallel workers (one task per row, like
+ * tokio::spawn(render_row) viewport.rs:236-240), threads <= 1 runs serially. */
+int rtw_oracle_render(const RtwCamera *cam, const RtwScene *scene, const RtwParams *params,
+                      float *out_rgb, RtwStats *stats, int threads);
+
+/* Viewport::new restated (viewport.rs:308-401); checked bit-for-bit against rtw_viewport_new(). */
+int rtw_oracle_viewport_new(uint32_t width, float aspect_ratio, const float *vfov, const float *origin,
+                            const float *direction, const float *vup, const float *lens_radius,
+                            RtwCamera *cam, uint32_t *height);
+
+/* One record per closest-hit query of a single path, for vector-level golden tests
+ * (Rust/cerr trace). */
+typedef struct RtwOracleBounce {
+    int32_t hit;             /* 1 hit, 0 miss (sky) */
+    int32_t sphere;          /* index of the sphere hit */
+    int32_t front_face;      /* !(dir . normal > 0)  */
+    int32_t cannot_refract;  /* dielectric only      */
+    float   t;
+    float   ratio;           /* refraction_ratio, dielectric only */
+    float   normal[3];       /* outward geometric normal */
+    float   point[3];
+    float   unit_dir[3];     /* unit(ray.direction) of the incoming ray */
+    float   next_dir[3];
+} RtwOracleBounce;
+
+/* Trace the path of one explicit ray (RNG stream = (seed, pixel, sample)); returns the number of
+ * records written (<= cap). */
+int rtw_oracle_trace_ray(const float origin[3], const float dir[3], float time,
+                         const RtwScene *scene, const RtwParams *params,
+                         uint32_t pixel, uint32_t sample,
+                         RtwOracleBounce *out, int cap, float rgb[3]);
+
+/* The RNG, exposed so tests can pin it with known-answer vectors. */
+void  rtw_oracle_rng_seed(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t state[2] /* state, inc */);
+float rtw_oracle_rng_next(uint32_t state[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,369 @@
+"""rtw-mi355x: MI355X-native path tracer behind the reference's Viewport/Scene/Sphere/Material surface.
+
+This package is a thin ctypes binding over ``librtw_hip.so`` (the product: hand-written HIP kernels
+for gfx950 + the C ABI of ``include/rtw.h`` + the C++ host mirror of the reference constructors).
+Python only moves pointers; it does no arithmetic on the render path, and there is NO CPU fallback:
+if the HIP library is missing or no GPU is present, rendering raises.
+
+Reference surface mirrored (names and argument meaning):
+  Viewport.new_from_res / Viewport.new      Rust/src/viewport.rs:308-428
+  Viewport.render / async_render            Rust/src/viewport.rs:215-248,430-478
+  Scene.new_sphere                          Rust/src/viewport.rs:90-105
+  Sphere.new / new_moving / new_with_texture Rust/src/objects/sphere.rs:151-247
+  METALLIC_M, SCATTER_M, FUZZY3_M, GLASS_M, GLASSR_M   Rust/src/objects/materials.rs:157-212
+
+The directory name carries a hyphen (it is fixed by the build contract); import it with
+``importlib.import_module("raytracing-in-a-weekend_amd")`` or through the ``rtw_amd`` alias module
+at the repo root.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtw_hip.so")
+
+# ---- enums (include/rtw.h) ---------------------------------------------------------------------
+RTW_OK = 0
+INTEGRATOR_GRADIENT, INTEGRATOR_BG_COLOR, INTEGRATOR_NORMAL, INTEGRATOR_FLAG = 0, 1, 2, 3
+SAMPLER_ROW, SAMPLER_STRATIFIED, SAMPLER_CENTRES, SAMPLER_NO_RAND = 0, 1, 2, 3
+ACCEL_BRUTE, ACCEL_BVH = 0, 1
+FLAG_RECURSIVE_ORDER = 1
+SCENE_C1, SCENE_C2, SCENE_C4, SCENE_C5, SCENE_METAL_TEST = 1, 2, 4, 5, 6
+
+# materials.rs:157-212 presets as (metallicness, opacity, ir)
+METALLIC_M = (1.0, 0.0, 1.0)
+SCATTER_M = (0.0, 0.0, 1.0)
+FUZZY3_M = (0.7, 0.0, 1.0)
+GLASS_M = (1.0, 1.0, 1.5)
+GLASSR_M = (1.0, 1.0, float(np.float32(1.0) / np.float32(1.5)))
+EMPTY_M = SCATTER_M
+
+
+class RtwError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        super().__init__(f"{what}: status {status} ({_strerror(status)})")
+        self.status = status
+
+
+# ---- PODs ----------------------------------------------------------------------------------------
+class RtwCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3),
+                ("pixel00", C.c_float * 3), ("delta_u", C.c_float * 3), ("delta_v", C.c_float * 3),
+                ("lens_radius", C.c_float), ("time0", C.c_float), ("shutter", C.c_float)]
+
+
+class RtwSphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("velocity", C.c_float * 3),
+                ("col_mod", C.c_float * 3), ("tex_color", C.c_float * 3),
+                ("metallicness", C.c_float), ("opacity", C.c_float), ("ir", C.c_float),
+                ("emitted", C.c_float * 3), ("tex", C.c_int32)]
+
+
+class RtwTexture(C.Structure):
+    _fields_ = [("row", C.c_uint32), ("col", C.c_uint32), ("texel_offset", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class RtwScene(C.Structure):
+    _fields_ = [("spheres", C.POINTER(RtwSphere)), ("textures", C.POINTER(RtwTexture)),
+                ("texels", C.POINTER(C.c_float)), ("n_spheres", C.c_uint32), ("n_textures", C.c_uint32),
+                ("n_texels", C.c_uint32), ("background", C.c_float * 3)]
+
+
+class RtwParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32), ("depth", C.c_uint32),
+                ("gamma", C.c_float), ("mint", C.c_float), ("maxt", C.c_float),
+                ("integrator", C.c_uint32), ("sampler", C.c_uint32), ("accel", C.c_uint32), ("flags", C.c_uint32),
+                ("seed", C.c_uint64),
+                ("row_block", C.c_uint32), ("part_index", C.c_uint32), ("part_count", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class RtwStats(C.Structure):
+    _fields_ = [("camera_rays", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("node_tests", C.c_uint64), ("nan_pixels", C.c_uint32), ("rows", C.c_uint32),
+                ("kernel_ms", C.c_float), ("total_ms", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load librtw_hip.so.  Fails loudly: there is no other implementation to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    L.rtw_abi_version.restype = C.c_int
+    L.rtw_device_count.restype = C.c_int
+    L.rtw_strerror.restype = C.c_char_p
+    L.rtw_strerror.argtypes = [C.c_int]
+    L.rtw_last_hip_error.restype = C.c_int
+    L.rtw_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.rtw_ctx_destroy.argtypes = [C.c_void_p]
+    L.rtw_ctx_destroy.restype = None
+    L.rtw_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.rtw_ctx_set_scene.argtypes = [C.c_void_p, C.POINTER(RtwScene), C.c_float, C.c_float]
+    L.rtw_ctx_render.argtypes = [C.c_void_p, C.POINTER(RtwCamera), C.POINTER(RtwParams), C.c_void_p, C.POINTER(RtwStats)]
+    L.rtw_render.argtypes = [C.POINTER(RtwCamera), C.POINTER(RtwScene), C.POINTER(RtwParams), C.c_void_p, C.POINTER(RtwStats)]
+    L.rtw_viewport_new.argtypes = [C.c_uint32, C.c_float, fp, fp, fp, fp, fp, C.POINTER(RtwCamera), C.POINTER(C.c_uint32)]
+    L.rtw_viewport_new_from_res.argtypes = [C.c_uint32, C.c_uint32, fp, fp, fp, fp, fp, C.POINTER(RtwCamera), C.POINTER(C.c_uint32)]
+    L.rtw_sphere_new.argtypes = [fp, C.c_float, fp, fp, fp, C.POINTER(RtwSphere)]
+    L.rtw_sphere_new_with_texture.argtypes = [fp, C.c_float, fp, fp, fp, C.c_int32, C.POINTER(RtwSphere)]
+    L.rtw_part_rows.restype = C.c_uint32
+    L.rtw_part_rows.argtypes = [C.c_uint32] * 4
+    L.rtw_quantize_u8.restype = None
+    L.rtw_quantize_u8.argtypes = [fp, C.c_size_t, C.POINTER(C.c_uint8)]
+    L.rtw_scene_generate.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(RtwSphere), C.c_uint32, C.POINTER(C.c_uint32),
+                                     C.POINTER(RtwTexture), C.c_uint32, C.POINTER(C.c_uint32),
+                                     fp, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.rtw_scene_default_view.argtypes = [C.c_uint32, C.POINTER(RtwCamera), C.POINTER(RtwParams)]
+    _lib = L
+    return L
+
+
+def _strerror(status: int) -> str:
+    try:
+        return lib().rtw_strerror(status).decode()
+    except Exception:  # library itself missing
+        return "?"
+
+
+def _check(status: int, what: str):
+    if status != RTW_OK:
+        raise RtwError(status, what)
+
+
+def _f3(v) -> Optional[C.Array]:
+    if v is None:
+        return None
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _fptr(arr):
+    return None if arr is None else C.cast(arr, C.POINTER(C.c_float))
+
+
+def _f1(v):
+    return None if v is None else C.pointer(C.c_float(float(v)))
+
+
+# ---- reference-shaped host objects ---------------------------------------------------------------
+class Sphere:
+    """`Sphere` of Rust/src/objects/sphere.rs:13-20 (constructors :151-247)."""
+
+    def __init__(self, pod: RtwSphere):
+        self.pod = pod
+
+    @staticmethod
+    def new(origin, r, col_mod=None, mat=None) -> "Sphere":
+        s = RtwSphere()
+        _check(lib().rtw_sphere_new(_fptr(_f3(origin)), float(r), _fptr(_f3(col_mod)), _fptr(_f3(mat)), None, C.byref(s)), "rtw_sphere_new")
+        return Sphere(s)
+
+    @staticmethod
+    def new_moving(origin, r, col_mod, mat, velocity) -> "Sphere":
+        s = RtwSphere()
+        _check(lib().rtw_sphere_new(_fptr(_f3(origin)), float(r), _fptr(_f3(col_mod)), _fptr(_f3(mat)), _fptr(_f3(velocity)), C.byref(s)), "rtw_sphere_new")
+        return Sphere(s)
+
+    @staticmethod
+    def new_with_texture(origin, r, col_mod, mat, tex_index: int, velocity=None) -> "Sphere":
+        s = RtwSphere()
+        _check(lib().rtw_sphere_new_with_texture(_fptr(_f3(origin)), float(r), _fptr(_f3(col_mod)), _fptr(_f3(mat)),
+                                                 _fptr(_f3(velocity)), int(tex_index), C.byref(s)), "rtw_sphere_new_with_texture")
+        return Sphere(s)
+
+    @staticmethod
+    def with_albedo(origin, r, albedo, mat=None, velocity=None) -> "Sphere":
+        """Albedo exactly `albedo` (texture = albedo, col_mod = 1): opts out of Sphere::new's c*c quirk."""
+        sp = Sphere.new_moving(origin, r, (1.0, 1.0, 1.0), mat, velocity or (0.0, 0.0, 0.0))
+        for k in range(3):
+            sp.pod.tex_color[k] = float(albedo[k])
+        return sp
+
+
+class Scene:
+    """`Scene::new_sphere(spheres)` (Rust/src/viewport.rs:90-105): spheres (+ image textures)."""
+
+    def __init__(self, spheres: Sequence, textures: Sequence[np.ndarray] = (), background=(0.0, 0.0, 0.0)):
+        pods = [s.pod if isinstance(s, Sphere) else s for s in spheres]
+        self._spheres = (RtwSphere * max(1, len(pods)))(*pods)
+        self.n_spheres = len(pods)
+        descs, flat, off = [], [], 0
+        for img in textures:                      # img: [col(height)][row(width)][3] float32
+            img = np.ascontiguousarray(img, dtype=np.float32)
+            h, w = img.shape[0], img.shape[1]
+            descs.append(RtwTexture(w, h, off, 0))
+            flat.append(img.reshape(-1, 3))
+            off += w * h
+        self._textures = (RtwTexture * max(1, len(descs)))(*descs)
+        self.n_textures = len(descs)
+        self._texels = np.concatenate(flat, axis=0).astype(np.float32) if flat else np.zeros((1, 3), np.float32)
+        self.n_texels = off
+        self.pod = RtwScene()
+        self.pod.spheres = C.cast(self._spheres, C.POINTER(RtwSphere))
+        self.pod.textures = C.cast(self._textures, C.POINTER(RtwTexture))
+        self.pod.texels = self._texels.ctypes.data_as(C.POINTER(C.c_float))
+        self.pod.n_spheres, self.pod.n_textures, self.pod.n_texels = self.n_spheres, self.n_textures, self.n_texels
+        for k in range(3):
+            self.pod.background[k] = float(background[k])
+
+    @staticmethod
+    def new_sphere(spheres: Sequence) -> "Scene":
+        return Scene(spheres)
+
+    @staticmethod
+    def generate(which: int, scene_seed: int = 42) -> "Scene":
+        """One of the BASELINE config scenes, laid out by the C++ host library."""
+        L = lib()
+        ns, nt, nx = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(L.rtw_scene_generate(which, scene_seed, None, 0, C.byref(ns), None, 0, C.byref(nt), None, 0, C.byref(nx)), "rtw_scene_generate")
+        sp = (RtwSphere * max(1, ns.value))()
+        tx = (RtwTexture * max(1, nt.value))()
+        tl = np.zeros((max(1, nx.value), 3), np.float32)
+        _check(L.rtw_scene_generate(which, scene_seed, sp, ns.value, C.byref(ns), tx, nt.value, C.byref(nt),
+                                    tl.ctypes.data_as(C.POINTER(C.c_float)), nx.value, C.byref(nx)), "rtw_scene_generate")
+        sc = Scene(list(sp)[: ns.value])
+        sc._textures, sc.n_textures, sc._texels, sc.n_texels = tx, nt.value, tl, nx.value
+        sc.pod.textures = C.cast(tx, C.POINTER(RtwTexture))
+        sc.pod.texels = tl.ctypes.data_as(C.POINTER(C.c_float))
+        sc.pod.n_textures, sc.pod.n_texels = nt.value, nx.value
+        return sc
+
+
+class Viewport:
+    """`Viewport` of Rust/src/viewport.rs:49-77; `new`/`new_from_res` are :308-428.
+
+    `render(ray_color, scene)` takes the integrator as an enum (a host closure cannot run on the GPU):
+    INTEGRATOR_GRADIENT == ray_color_gradient, INTEGRATOR_BG_COLOR == ray_color_bg_color.
+    """
+
+    def __init__(self, cam: RtwCamera, width: int, height: int, samples: int, depth: int, gamma: float):
+        self.cam, self.width, self.height = cam, width, height
+        self.samples, self.depth, self.gamma = samples, depth, gamma
+        self.shutter_speed, self.fps, self.frame = 0.0, 30.0, 0
+        self.seed = 1
+        self.mint, self.maxt = 0.001, 100000.0
+
+    @staticmethod
+    def new(width, aspect_ratio, samples, depth, gamma, vfov=None, origin=None, direction=None, vup=None, msg=None, lens_radius=None):
+        cam, h = RtwCamera(), C.c_uint32()
+        _check(lib().rtw_viewport_new(int(width), float(aspect_ratio), _f1(vfov), _fptr(_f3(origin)), _fptr(_f3(direction)),
+                                      _fptr(_f3(vup)), _f1(lens_radius), C.byref(cam), C.byref(h)), "rtw_viewport_new")
+        return Viewport(cam, int(width), h.value, samples, depth, gamma)
+
+    @staticmethod
+    def new_from_res(width, height, samples, depth, gamma, vfov=None, origin=None, direction=None, vup=None, msg=None, lens_radius=None):
+        cam, h = RtwCamera(), C.c_uint32()
+        _check(lib().rtw_viewport_new_from_res(int(width), int(height), _f1(vfov), _fptr(_f3(origin)), _fptr(_f3(direction)),
+                                               _fptr(_f3(vup)), _f1(lens_radius), C.byref(cam), C.byref(h)), "rtw_viewport_new_from_res")
+        return Viewport(cam, int(width), h.value, samples, depth, gamma)
+
+    def params(self, integrator=INTEGRATOR_GRADIENT, sampler=SAMPLER_STRATIFIED, accel=ACCEL_BVH) -> RtwParams:
+        p = RtwParams()
+        p.width, p.height, p.samples, p.depth = self.width, self.height, self.samples, self.depth
+        p.gamma, p.mint, p.maxt = self.gamma, self.mint, self.maxt
+        p.integrator, p.sampler, p.accel, p.flags, p.seed = integrator, sampler, accel, 0, self.seed
+        p.row_block, p.part_index, p.part_count = 8, 0, 1
+        return p
+
+    def camera(self) -> RtwCamera:
+        cam = RtwCamera.from_buffer_copy(self.cam)
+        cam.time0 = float(np.float32(self.frame) / np.float32(self.fps))    # viewport.rs:279
+        cam.shutter = float(self.shutter_speed)
+        return cam
+
+    def render(self, ray_color: int, scene: Scene, device: int = 0, accel: int = ACCEL_BVH) -> np.ndarray:
+        """Viewport::render (stratified, serial in the reference; viewport.rs:430-478) -> [H][W][3] f32."""
+        return self._render(ray_color, SAMPLER_STRATIFIED, scene, device, accel)
+
+    def async_render(self, ray_color: int, scene: Scene, device: int = 0, accel: int = ACCEL_BVH) -> np.ndarray:
+        """async_render / render_row (viewport.rs:215-305): exactly `samples` rays, shutter time."""
+        return self._render(ray_color, SAMPLER_ROW, scene, device, accel)
+
+    def render_no_rand(self, ray_color: int, scene: Scene, device: int = 0, accel: int = ACCEL_BVH) -> np.ndarray:
+        return self._render(ray_color, SAMPLER_NO_RAND, scene, device, accel)
+
+    def _render(self, ray_color, sampler, scene, device, accel):
+        with Renderer(device) as r:
+            cam = self.camera()
+            r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
+            img, _ = r.render(cam, self.params(ray_color, sampler, accel))
+        return img
+
+
+class Renderer:
+    """One `rtw_ctx`: one GPU, one stream, device-resident scene + BVH."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().rtw_ctx_create(int(device), C.byref(self._h)), "rtw_ctx_create")
+        self._scene = None
+
+    def close(self):
+        if self._h:
+            lib().rtw_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: int):
+        _check(lib().rtw_ctx_set_stream(self._h, C.c_void_p(hip_stream)), "rtw_ctx_set_stream")
+
+    def set_scene(self, scene: Scene, t_begin: float = 0.0, t_end: float = 0.0):
+        self._scene = scene     # keep host arrays alive
+        _check(lib().rtw_ctx_set_scene(self._h, C.byref(scene.pod), float(t_begin), float(t_end)), "rtw_ctx_set_scene")
+
+    def render(self, cam: RtwCamera, params: RtwParams, out=None):
+        """Render into `out`: None -> new numpy array; numpy array -> host buffer; int -> raw device pointer
+        (e.g. torch_tensor.data_ptr()) of [rows][width][3] f32.  Returns (out, RtwStats)."""
+        rows = lib().rtw_part_rows(params.height, params.row_block, params.part_index, params.part_count)
+        st = RtwStats()
+        if out is None:
+            out = np.empty((rows, params.width, 3), np.float32)
+        if isinstance(out, np.ndarray):
+            assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.size == rows * params.width * 3
+            ptr = C.c_void_p(out.ctypes.data)
+        else:
+            ptr = C.c_void_p(int(out))
+        _check(lib().rtw_ctx_render(self._h, C.byref(cam), C.byref(params), ptr, C.byref(st)), "rtw_ctx_render")
+        return out, st
+
+
+def default_view(which: int):
+    cam, p = RtwCamera(), RtwParams()
+    _check(lib().rtw_scene_default_view(which, C.byref(cam), C.byref(p)), "rtw_scene_default_view")
+    return cam, p
+
+
+def quantize_u8(img: np.ndarray) -> np.ndarray:
+    """write_img_f32's 8-bit rule (Rust/src/write_img.rs:11-15)."""
+    a = np.ascontiguousarray(img, np.float32)
+    out = np.empty(a.shape, np.uint8)
+    lib().rtw_quantize_u8(a.ctypes.data_as(C.POINTER(C.c_float)), a.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def device_count() -> int:
+    return int(lib().rtw_device_count())

@@ -1,0 +1,456 @@
+// rtw_host.cpp -- host mirror of the reference's constructors + scene generators + BVH build.
+// Built with -ffp-contract=off: every f32 expression below rounds once per written operation,
+// like the Rust it restates.
+#include "rtw_host.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rtw {
+
+uint32_t sampler_count(uint32_t sampler, uint32_t samples, uint32_t *s_root) {
+    uint32_t root = 0, n = samples;
+    if (sampler == RTW_SAMPLER_STRATIFIED) { root = (uint32_t)std::ceil(std::sqrt((float)samples)); n = root * root; }      // viewport.rs:443
+    else if (sampler == RTW_SAMPLER_CENTRES) { root = (uint32_t)std::floor(std::sqrt((float)samples)); n = root * root; }   // Rust2 viewport.rs:90
+    else if (sampler == RTW_SAMPLER_NO_RAND) n = 1;
+    if (s_root) *s_root = root;
+    return n;
+}
+
+namespace {
+
+struct V { float x, y, z; };
+inline V mk(float x, float y, float z) { return V{ x, y, z }; }
+inline V ld(const float *p) { return V{ p[0], p[1], p[2] }; }
+inline V operator+(V a, V b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V operator-(V a, V b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V operator*(V a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+inline V operator/(V a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+inline V operator-(V a) { return mk(-a.x, -a.y, -a.z); }
+inline float length(V a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline V unit(V a) { return a / length(a); }
+inline V cross(V a, V b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline void st(float *p, V a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+
+// Rust `f as u64` for the values that occur here (saturating, NaN -> 0)
+inline uint32_t f32_as_u(float f) {
+    if (!(f > 0.0f)) return 0;
+    if (f >= 4294967040.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+
+// ---- scene RNG: PCG32 (XSH-RR 64/32), only used to lay scenes out --------------------------------
+struct Pcg32 {
+    uint64_t state, inc;
+    explicit Pcg32(uint64_t seed, uint64_t seq = 54u) {
+        state = 0u; inc = (seq << 1u) | 1u; next(); state += seed; next();
+    }
+    uint32_t next() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+    }
+    float f() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }
+    float range(float lo, float hi) { return lo + (hi - lo) * f(); }
+};
+
+const float SCATTER_M[3] = { 0.0f, 0.0f, 1.0f };          // materials.rs:168-177
+const float METALLIC_M[3] = { 1.0f, 0.0f, 1.0f };         // :157-166
+const float FUZZY3_M[3] = { 0.7f, 0.0f, 1.0f };           // :179-188
+const float GLASS_M[3] = { 1.0f, 1.0f, 1.5f };            // :190-199
+const float GLASSR_M[3] = { 1.0f, 1.0f, 1.0f / 1.5f };    // :201-210
+
+// Sphere::new(origin, r, Some(c), Some(mat)): col_mod AND the 1x1 texture are c (sphere.rs:151-173)
+RtwSphere sphere_new(V o, float r, V c, const float *mat) {
+    RtwSphere s; std::memset(&s, 0, sizeof s);
+    float org[3] = { o.x, o.y, o.z }, col[3] = { c.x, c.y, c.z };
+    rtw_sphere_new(org, r, col, mat, nullptr, &s);
+    return s;
+}
+// A sphere whose reported albedo is exactly c: texture = c, col_mod = (1,1,1)
+// (== Sphere::new_with_texture(o, r, None, mat, ImageTexture::from_color(c)))
+RtwSphere sphere_albedo(V o, float r, V c, const float *mat) {
+    RtwSphere s = sphere_new(o, r, mk(1, 1, 1), mat);
+    st(s.tex_color, c);
+    return s;
+}
+
+} // namespace
+} // namespace rtw
+
+using namespace rtw;
+
+extern "C" {
+
+uint32_t rtw_part_rows(uint32_t height, uint32_t row_block, uint32_t part_index, uint32_t part_count) {
+    if (part_count <= 1) return height;
+    if (row_block == 0 || part_index >= part_count) return 0;
+    uint32_t n = 0;
+    for (uint32_t r = 0; r < height; r++) if ((r / row_block) % part_count == part_index) n++;
+    return n;
+}
+
+void rtw_quantize_u8(const float *rgb, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        float v = rgb[i] * 255.0f;                      // write_img.rs:11-15
+        v = v != v ? v : (v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));   // clamp (NaN propagates)
+        v = std::round(v);                              // f32::round: half away from zero
+        out[i] = v != v ? 0 : (uint8_t)v;               // `as u8`: NaN -> 0
+    }
+}
+
+// Viewport::new (viewport.rs:308-401)
+int rtw_viewport_new(uint32_t width, float aspect_ratio, const float *vfov, const float *origin,
+                     const float *direction, const float *vup, const float *lens_radius,
+                     RtwCamera *cam, uint32_t *height_out) {
+    if (!cam || width == 0) return RTW_E_INVALID;
+    V c_origin = origin ? ld(origin) : mk(0.0f, 0.0f, 0.0f);
+    V c_dir = direction ? ld(direction) : mk(0.0f, 0.0f, -1.0f);
+    V c_vup = vup ? ld(vup) : mk(0.0f, 1.0f, 0.0f);
+    float c_vfov = vfov ? *vfov : 90.0f;
+
+    V w = -c_dir;                                          // :342, NOT normalised
+    V u = unit(cross(c_vup, w));
+    V v = cross(w, u);
+
+    uint32_t height = f32_as_u((float)width / aspect_ratio);   // :346
+
+    float h = std::tan(c_vfov * 3.14159265358979323846f / 360.0f);   // :348
+    float viewport_height = 2.0f * h;
+    float viewport_width = aspect_ratio * viewport_height;  // focal length is not applied (:349-351)
+
+    V viewport_u = u * viewport_width;
+    V viewport_v = (-v) * viewport_height;
+    V pixel_delta_u = viewport_u / (float)width;
+    V pixel_delta_v = viewport_v / (float)height;
+    V viewport_upper_left = ((-w) - viewport_u / 2.0f) - viewport_v / 2.0f;      // :359, a direction
+    V pixel00_loc = viewport_upper_left + (pixel_delta_u + pixel_delta_v) * 0.5f;
+
+    std::memset(cam, 0, sizeof *cam);
+    st(cam->origin, c_origin); st(cam->u, u); st(cam->v, v);
+    st(cam->pixel00, pixel00_loc); st(cam->delta_u, pixel_delta_u); st(cam->delta_v, pixel_delta_v);
+    cam->lens_radius = lens_radius ? *lens_radius : 0.0f;
+    cam->time0 = 0.0f / 30.0f;      // frame 0, fps 30 (:395-399)
+    cam->shutter = 0.0f;
+    if (height_out) *height_out = height;
+    return RTW_OK;
+}
+
+int rtw_viewport_new_from_res(uint32_t width, uint32_t height, const float *vfov, const float *origin,
+                              const float *direction, const float *vup, const float *lens_radius,
+                              RtwCamera *cam, uint32_t *height_out) {
+    if (height == 0) return RTW_E_INVALID;
+    return rtw_viewport_new(width, (float)width / (float)height, vfov, origin, direction, vup, lens_radius, cam, height_out);
+}
+
+int rtw_sphere_new(const float origin[3], float radius, const float *col_mod, const float *mat3,
+                   const float *velocity, RtwSphere *out) {
+    if (!origin || !out) return RTW_E_INVALID;
+    std::memset(out, 0, sizeof *out);
+    const float one[3] = { 1.0f, 1.0f, 1.0f };
+    const float *c = col_mod ? col_mod : one;
+    const float *m = mat3 ? mat3 : SCATTER_M;           // EMPTY_M == SCATTER_M (materials.rs:212)
+    for (int k = 0; k < 3; k++) {
+        out->center[k] = origin[k];
+        out->col_mod[k] = c[k];
+        out->tex_color[k] = c[k];                        // ImageTexture::from_color(col_mod) (sphere.rs:168-171)
+        out->velocity[k] = velocity ? velocity[k] : 0.0f;
+    }
+    out->radius = radius;
+    out->metallicness = m[0]; out->opacity = m[1]; out->ir = m[2];
+    out->tex = -1;
+    return RTW_OK;
+}
+
+int rtw_sphere_new_with_texture(const float origin[3], float radius, const float *col_mod, const float *mat3,
+                                const float *velocity, int32_t tex, RtwSphere *out) {
+    int rc = rtw_sphere_new(origin, radius, col_mod, mat3, velocity, out);
+    if (rc != RTW_OK) return rc;
+    out->tex = tex;
+    out->tex_color[0] = out->tex_color[1] = out->tex_color[2] = 1.0f;
+    return RTW_OK;
+}
+
+// ---- scene generators.  None of these scenes exists in the reference; they are
+// expressed with the reference's Sphere::new / material presets. ------------------------------------
+static void book1_small_spheres(Pcg32 &rng, std::vector<RtwSphere> &out, bool moving) {
+    for (int a = -11; a < 11; a++) {
+        for (int b = -11; b < 11; b++) {
+            float choose = rng.f();
+            V centre = mk((float)a + 0.9f * rng.f(), 0.2f, (float)b + 0.9f * rng.f());
+            if (!(length(centre - mk(4.0f, 0.2f, 0.0f)) > 0.9f)) continue;
+            if (choose < 0.8f) {
+                V albedo = mk(rng.f() * rng.f(), rng.f() * rng.f(), rng.f() * rng.f());
+                RtwSphere s = sphere_albedo(centre, 0.2f, albedo, SCATTER_M);
+                if (moving) s.velocity[1] = rng.range(0.0f, 0.5f) * 30.0f;   // centre + (0, U[0,.5), 0) over one 1/30 s shutter
+                out.push_back(s);
+            } else if (choose < 0.95f) {
+                V albedo = mk(rng.range(0.5f, 1.0f), rng.range(0.5f, 1.0f), rng.range(0.5f, 1.0f));
+                float fuzz = rng.range(0.0f, 0.5f);
+                const float m[3] = { 1.0f - fuzz, 0.0f, 1.0f };   // closest analogue of book fuzz: lerp toward lambert
+                out.push_back(sphere_albedo(centre, 0.2f, albedo, m));
+            } else {
+                out.push_back(sphere_albedo(centre, 0.2f, mk(1, 1, 1), GLASS_M));
+            }
+        }
+    }
+    out.push_back(sphere_albedo(mk(0, 1, 0), 1.0f, mk(1, 1, 1), GLASS_M));
+    out.push_back(sphere_albedo(mk(-4, 1, 0), 1.0f, mk(0.4f, 0.2f, 0.1f), SCATTER_M));
+    out.push_back(sphere_albedo(mk(4, 1, 0), 1.0f, mk(0.7f, 0.6f, 0.5f), METALLIC_M));
+}
+
+int rtw_scene_generate(uint32_t which, uint64_t scene_seed,
+                       RtwSphere *spheres, uint32_t sphere_cap, uint32_t *n_spheres,
+                       RtwTexture *textures, uint32_t texture_cap, uint32_t *n_textures,
+                       float *texels, uint32_t texel_cap, uint32_t *n_texels) {
+    std::vector<RtwSphere> sp; std::vector<RtwTexture> tx; std::vector<float> tl;
+    Pcg32 rng(scene_seed);
+    switch (which) {
+    case RTW_SCENE_C1_THREE_SPHERES:
+        sp.push_back(sphere_new(mk(0, -100.5f, -1), 100.0f, mk(0.8f, 0.8f, 0.0f), SCATTER_M));
+        sp.push_back(sphere_new(mk(0, 0, -1), 0.5f, mk(0.7f, 0.3f, 0.3f), SCATTER_M));
+        sp.push_back(sphere_new(mk(1, 0, -1), 0.5f, mk(0.8f, 0.6f, 0.2f), METALLIC_M));
+        break;
+    case RTW_SCENE_METAL_TEST:    // material_tests.rs:105-167
+        sp.push_back(sphere_new(mk(-1, 0, -1), 0.5f, mk(0.8f, 0.8f, 0.8f), FUZZY3_M));
+        sp.push_back(sphere_new(mk(1, 0, -1), 0.5f, mk(0.8f, 0.6f, 0.2f), METALLIC_M));
+        sp.push_back(sphere_new(mk(0, 0, -1), 0.5f, mk(0.7f, 0.3f, 0.3f), SCATTER_M));
+        sp.push_back(sphere_new(mk(0, -100.5f, -1), 100.0f, mk(0.8f, 0.8f, 0.0f), SCATTER_M));
+        break;
+    case RTW_SCENE_C2_BOOK1_FINAL:
+        sp.push_back(sphere_albedo(mk(0, -1000, 0), 1000.0f, mk(0.5f, 0.5f, 0.5f), SCATTER_M));
+        book1_small_spheres(rng, sp, false);
+        break;
+    case RTW_SCENE_C5_MOTION_CHECKER: {
+        // ground: 4x2 two-colour image through the sphere-UV lookup (squares.png-like, texture.rs:259-267)
+        RtwTexture t; t.row = 4; t.col = 2; t.texel_offset = 0; t.reserved = 0; tx.push_back(t);
+        for (int y = 0; y < 2; y++) for (int x = 0; x < 4; x++) {
+            bool dark = ((x + y) & 1) != 0;
+            const float c[3] = { dark ? 0.2f : 0.9f, dark ? 0.3f : 0.9f, dark ? 0.1f : 0.9f };
+            tl.insert(tl.end(), c, c + 3);
+        }
+        RtwSphere g; const float o[3] = { 0, -1000, 0 };
+        rtw_sphere_new_with_texture(o, 1000.0f, nullptr, SCATTER_M, nullptr, 0, &g);
+        sp.push_back(g);
+        book1_small_spheres(rng, sp, true);
+        break;
+    }
+    case RTW_SCENE_C4_DIELECTRIC: {
+        sp.push_back(sphere_albedo(mk(0, -1000, 0), 1000.0f, mk(0.5f, 0.5f, 0.5f), SCATTER_M));
+        for (int a = -4; a <= 4; a++) for (int b = -4; b <= 4; b++) {   // material_tests.rs:215-250 hollow-glass pattern
+            V c = mk(1.1f * (float)a, 0.45f, 1.1f * (float)b);
+            sp.push_back(sphere_albedo(c, 0.45f, mk(1, 1, 1), GLASS_M));
+            sp.push_back(sphere_albedo(c, 0.35f, mk(1, 1, 1), GLASSR_M));
+        }
+        for (int k = 0; k < 20; k++) {
+            V c = mk(rng.range(-6.0f, 6.0f), 1.3f + 0.3f * rng.f(), rng.range(-6.0f, 6.0f));
+            V albedo = mk(rng.range(0.5f, 1.0f), rng.range(0.5f, 1.0f), rng.range(0.5f, 1.0f));
+            sp.push_back(sphere_albedo(c, 0.3f, albedo, FUZZY3_M));
+        }
+        break;
+    }
+    default: return RTW_E_INVALID;
+    }
+    if (n_spheres) *n_spheres = (uint32_t)sp.size();
+    if (n_textures) *n_textures = (uint32_t)tx.size();
+    if (n_texels) *n_texels = (uint32_t)(tl.size() / 3);
+    if (!spheres) return RTW_OK;     // count query
+    if (sphere_cap < sp.size() || texture_cap < tx.size() || texel_cap < tl.size() / 3) return RTW_E_INVALID;
+    if ((!tx.empty() && !textures) || (!tl.empty() && !texels)) return RTW_E_INVALID;
+    std::copy(sp.begin(), sp.end(), spheres);
+    if (!tx.empty()) std::copy(tx.begin(), tx.end(), textures);
+    if (!tl.empty()) std::copy(tl.begin(), tl.end(), texels);
+    return RTW_OK;
+}
+
+int rtw_scene_default_view(uint32_t which, RtwCamera *cam, RtwParams *p) {
+    if (!cam || !p) return RTW_E_INVALID;
+    std::memset(p, 0, sizeof *p);
+    p->gamma = 2.0f; p->mint = 0.001f; p->maxt = 100000.0f;     // ray_color_gradient (ray_color.rs:17-18)
+    p->integrator = RTW_INTEGRATOR_GRADIENT; p->sampler = RTW_SAMPLER_ROW; p->accel = RTW_ACCEL_BVH;
+    p->seed = 1; p->row_block = 8; p->part_index = 0; p->part_count = 1;
+    uint32_t h = 0;
+    if (which == RTW_SCENE_C1_THREE_SPHERES || which == RTW_SCENE_METAL_TEST) {
+        p->width = 400; p->height = 225; p->depth = 10;
+        p->samples = which == RTW_SCENE_METAL_TEST ? 100 : 10;
+        if (which == RTW_SCENE_METAL_TEST) { p->sampler = RTW_SAMPLER_STRATIFIED; p->maxt = 1000.0f; }   // viewport.render(&ray_color_d) material_tests.rs:165
+        return rtw_viewport_new_from_res(p->width, p->height, nullptr, nullptr, nullptr, nullptr, nullptr, cam, &h);
+    }
+    // Book-1 framing: look from (13,2,3) at the origin, vfov 20, aperture 0.1 (lens_radius 0.05).
+    // The reference does not normalise `direction`: w = -direction and v = w x u inherit its length
+    // (viewport.rs:342-344), and the focal length is never applied (:349-351), so the only
+    // undistorted view is a UNIT direction (focus plane at distance 1; lens rays of a pixel stay
+    // parallel, i.e. a constant 0.05-unit blur rather than a focus distance of 10).
+    const float from[3] = { 13.0f, 2.0f, 3.0f };
+    const float len = std::sqrt(13.0f * 13.0f + 2.0f * 2.0f + 3.0f * 3.0f);
+    const float dir[3] = { -13.0f / len, -2.0f / len, -3.0f / len };
+    const float vfov = 20.0f;
+    const float lens = 0.05f;
+    p->depth = 50;
+    switch (which) {
+    case RTW_SCENE_C2_BOOK1_FINAL: p->width = 1200; p->height = 675; p->samples = 100; break;
+    case RTW_SCENE_C4_DIELECTRIC: p->width = 1920; p->height = 1080; p->samples = 1000; break;
+    case RTW_SCENE_C5_MOTION_CHECKER: p->width = 1920; p->height = 1080; p->samples = 500; break;
+    default: return RTW_E_INVALID;
+    }
+    int rc = rtw_viewport_new_from_res(p->width, p->height, &vfov, from, dir, nullptr, &lens, cam, &h);
+    if (rc != RTW_OK) return rc;
+    if (which == RTW_SCENE_C5_MOTION_CHECKER) { cam->time0 = 0.0f / 30.0f; cam->shutter = 1.0f / 30.0f; }   // frame 0, fps 30, shutter 1/fps
+    return RTW_OK;
+}
+
+} // extern "C"
+
+// ---- BVH build ------------------------------------------------------------------------------------
+namespace rtw {
+namespace {
+
+struct Box { float lo[3], hi[3]; };
+inline void box_empty(Box &b) { for (int k = 0; k < 3; k++) { b.lo[k] = FLT_MAX; b.hi[k] = -FLT_MAX; } }
+inline void box_grow(Box &b, const Box &o) { for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); } }
+inline float box_area(const Box &b) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+struct Prim { Box box; float cen[3]; uint32_t sphere; };
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<BvhNode> nodes;
+    uint32_t max_depth = 0;
+
+    // returns child reference (>= 0 node, < 0 ~sphere) and its box
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth, Box &out_box) {
+        max_depth = std::max(max_depth, depth);
+        Box bb; box_empty(bb);
+        for (uint32_t i = first; i < first + count; i++) box_grow(bb, prims[i].box);
+        out_box = bb;
+        if (count == 1) return ~(int32_t)prims[first].sphere;
+
+        // binned SAH over centroids
+        Box cb; box_empty(cb);
+        for (uint32_t i = first; i < first + count; i++)
+            for (int k = 0; k < 3; k++) { cb.lo[k] = std::min(cb.lo[k], prims[i].cen[k]); cb.hi[k] = std::max(cb.hi[k], prims[i].cen[k]); }
+        uint32_t mid = first + count / 2;
+        int best_axis = -1; float best_cost = FLT_MAX; float best_split = 0.0f;
+        const int NB = 16;
+        if (depth + 4 < RTW_BVH_STACK) {
+            for (int ax = 0; ax < 3; ax++) {
+                float ext = cb.hi[ax] - cb.lo[ax];
+                if (!(ext > 0.0f)) continue;
+                Box bins[NB]; uint32_t cnt[NB];
+                for (int b = 0; b < NB; b++) { box_empty(bins[b]); cnt[b] = 0; }
+                for (uint32_t i = first; i < first + count; i++) {
+                    int b = (int)((prims[i].cen[ax] - cb.lo[ax]) / ext * NB);
+                    b = std::min(std::max(b, 0), NB - 1);
+                    box_grow(bins[b], prims[i].box); cnt[b]++;
+                }
+                float right_area[NB]; uint32_t right_cnt[NB];
+                Box acc; box_empty(acc); uint32_t c = 0;
+                for (int b = NB - 1; b > 0; b--) { box_grow(acc, bins[b]); c += cnt[b]; right_area[b] = c ? box_area(acc) : 0.0f; right_cnt[b] = c; }
+                box_empty(acc); c = 0;
+                for (int b = 0; b < NB - 1; b++) {
+                    box_grow(acc, bins[b]); c += cnt[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = box_area(acc) * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = cb.lo[ax] + ext * (float)(b + 1) / NB; }
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            auto it = std::partition(prims.begin() + first, prims.begin() + first + count,
+                                     [&](const Prim &p) { return p.cen[best_axis] < best_split; });
+            mid = (uint32_t)(it - prims.begin());
+        }
+        if (best_axis < 0 || mid == first || mid == first + count) {
+            // median split on the widest centroid axis (also the depth-limit fallback)
+            int ax = 0;
+            for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
+            mid = first + count / 2;
+            std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                             [&](const Prim &a, const Prim &b) { return a.cen[ax] < b.cen[ax]; });
+        }
+        uint32_t me = (uint32_t)nodes.size();
+        nodes.push_back(BvhNode{});
+        Box b0, b1;
+        int32_t c0 = build(first, mid - first, depth + 1, b0);
+        int32_t c1 = build(mid, first + count - mid, depth + 1, b1);
+        BvhNode &n = nodes[me];
+        for (int k = 0; k < 3; k++) { n.lo0[k] = b0.lo[k]; n.hi0[k] = b0.hi[k]; n.lo1[k] = b1.lo[k]; n.hi1[k] = b1.hi[k]; }
+        n.c0 = c0; n.c1 = c1; n.pad[0] = n.pad[1] = 0;
+        return (int32_t)me;
+    }
+};
+
+} // namespace
+
+void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end, BvhBuild &out) {
+    out.nodes.clear(); out.big.clear();
+    out.root = std::numeric_limits<int32_t>::min();
+    out.centre[0] = out.centre[1] = out.centre[2] = 0.0f;
+    out.centre_radius = 0.0f; out.r_min = 0.0f; out.r_max = 0.0f; out.abs_max = 0.0f; out.depth = 0;
+    if (n == 0) return;
+
+    // "big" spheres: radius >= 16 x the median radius, at most RTW_MAX_BIG of them (largest first)
+    std::vector<float> radii(n);
+    for (uint32_t i = 0; i < n; i++) radii[i] = std::fabs(spheres[i].radius);
+    std::vector<float> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const float r_med = sorted[n / 2];
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return radii[a] > radii[b]; });
+    std::vector<char> is_big(n, 0);
+    if (n > 2) {
+        for (uint32_t k = 0; k < n && out.big.size() < RTW_MAX_BIG; k++) {
+            uint32_t i = order[k];
+            if (!(radii[i] >= 16.0f * r_med) && std::isfinite(radii[i])) break;
+            is_big[i] = 1; out.big.push_back(i);
+        }
+    }
+    std::sort(out.big.begin(), out.big.end());
+
+    Builder b;
+    Box centres; box_empty(centres);
+    float rmin = FLT_MAX, rmax = 0.0f;
+    for (uint32_t i = 0; i < n; i++) {
+        if (is_big[i]) continue;
+        const RtwSphere &s = spheres[i];
+        Prim p; p.sphere = i;
+        for (int k = 0; k < 3; k++) {
+            // centre(t) = fl(origin + fl(velocity * t)) is monotone in t: the two ends bound it
+            float c0 = s.center[k] + s.velocity[k] * t_begin;
+            float c1 = s.center[k] + s.velocity[k] * t_end;
+            float lo = std::min(c0, c1), hi = std::max(c0, c1);
+            if (!(lo == lo) || !(hi == hi)) { lo = -FLT_MAX; hi = FLT_MAX; }
+            centres.lo[k] = std::min(centres.lo[k], lo); centres.hi[k] = std::max(centres.hi[k], hi);
+            p.cen[k] = 0.5f * lo + 0.5f * hi;
+            p.box.lo[k] = std::nextafter(lo - radii[i], -FLT_MAX);
+            p.box.hi[k] = std::nextafter(hi + radii[i], FLT_MAX);
+        }
+        rmin = std::min(rmin, radii[i]); rmax = std::max(rmax, radii[i]);
+        b.prims.push_back(p);
+    }
+    if (b.prims.empty()) return;
+    Box root_box;
+    out.root = b.build(0, (uint32_t)b.prims.size(), 0, root_box);
+    out.nodes.swap(b.nodes);
+    out.depth = b.max_depth;
+    double r2 = 0.0;
+    for (int k = 0; k < 3; k++) {
+        out.centre[k] = 0.5f * centres.lo[k] + 0.5f * centres.hi[k];
+        double h = std::max(std::fabs((double)centres.hi[k] - out.centre[k]), std::fabs((double)centres.lo[k] - out.centre[k]));
+        r2 += h * h;
+        out.abs_max = std::max(out.abs_max, std::max(std::fabs(root_box.lo[k]), std::fabs(root_box.hi[k])));
+    }
+    out.centre_radius = (float)(std::sqrt(r2) * 1.000001);
+    out.r_min = rmin; out.r_max = rmax;
+}
+
+} // namespace rtw

@@ -1,0 +1,47 @@
+// rtw_host.h -- host-side C++ mirror of the reference constructors (Viewport::new, Sphere::new,
+// Scene::new_sphere's acceleration build) and the BASELINE scene generators.  Pure host code.
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "rtw.h"
+
+namespace rtw {
+
+// f32 helpers: this library is built with -ffp-contract=off, so these are single IEEE operations.
+static inline float host_mul(float a, float b) { return a * b; }
+static inline float host_div(float a, float b) { return a / b; }
+
+// Rays per pixel a sampler traces for Viewport.samples (viewport.rs:443; Rust2 viewport.rs:90).
+uint32_t sampler_count(uint32_t sampler, uint32_t samples, uint32_t *s_root);
+
+// ---- acceleration structure ---------------------------------------------------------------------
+// Binary BVH, single-sphere leaves, both child boxes stored in the parent (one 64-byte fetch per
+// visit = two slab tests).  child >= 0: inner node index; child < 0: leaf holding sphere ~child.
+struct BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t c0, c1;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+#define RTW_MAX_BIG 16        // spheres far larger than the rest are tested exactly, outside the tree
+#define RTW_BVH_STACK 32      // builder guarantees depth <= RTW_BVH_STACK
+
+struct BvhBuild {
+    std::vector<BvhNode> nodes;          // nodes[0] is the root (absent when < 2 tree spheres)
+    std::vector<uint32_t> big;           // sphere indices tested by the uniform pre-pass
+    int32_t root;                        // node index, or ~sphere for a single tree sphere, or INT32_MIN if empty
+    // per-ray padding constants (DESIGN.md "Conservative traversal"): over the TREE spheres only
+    float centre[3];                     // C: centre of the box of sphere centres
+    float centre_radius;                 // R_c: max |c_s - C| (time-expanded)
+    float r_min, r_max;                  // radius range of the tree spheres
+    float abs_max;                       // largest |coordinate| of any tree box
+    uint32_t depth;
+};
+
+// Bounds cover centre(t) = origin + velocity * t for t in [t_begin, t_end] (sphere.rs:100); the
+// reference's own AABB ignores velocity (aabb/aabb.rs:27-39) and so culls moving spheres wrongly.
+void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end, BvhBuild &out);
+
+} // namespace rtw

@@ -1,0 +1,49 @@
+// rtw_kernels.h -- kernel argument block shared by rtw_kernels.hip (device) and rtw_shim.hip (host).
+#pragma once
+#include "rtw_device.h"
+#include "rtw_host.h"
+
+#define RTW_BLOCK 256   // 4 waves per workgroup
+
+namespace rtw {
+
+// Device view of the acceleration structure built by build_bvh() (rtw_host.cpp).
+struct DevBvh {
+    const BvhNode *nodes;
+    const f4 *big_geom;           // {cx, cy, cz, r*r} of the spheres kept outside the tree
+    const f4 *big_vel;
+    const uint32_t *big_index;    // their indices in the scene list
+    uint32_t n_big;
+    int32_t root;                 // node index; ~sphere when the tree is a single leaf; INT32_MIN when empty
+    float cx, cy, cz;             // centre C of the tree spheres' centres
+    float centre_radius;          // R_c
+    float r_max2;                 // r_max^2
+    float inv_2rmin;              // 1 / (2 r_min), +inf when r_min == 0
+    float abs_max;                // largest |coordinate| of the root box
+};
+
+struct KArgs {
+    RtwCamera cam;
+    DevScene  sc;
+    DevBvh    bvh;
+    uint32_t width, height;       // full image
+    uint32_t n_rows;              // rows of this partition (compact)
+    uint32_t row_block, part_index, part_count;
+    uint32_t tiles_x;             // ceil(width / 8)
+    uint32_t total_work;          // 64 * tiles_x * ceil(n_rows / 8)
+    uint32_t n_samples;           // rays per pixel actually traced (sampler-dependent)
+    uint32_t s_root;              // strata per axis (STRATIFIED / CENTRES)
+    uint32_t sampler, integrator, depth;
+    uint32_t seed_lo, seed_hi;
+    float inv_gamma, mint, maxt;
+    float bg[3];
+    float *out;                   // [n_rows][width][3]
+    uint32_t *queue;              // work-item counter, zeroed before launch
+    unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels
+};
+
+void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream);
+// Resident workgroups per CU for the kernel variant (occupancy API), >= 1.
+uint32_t kernel_blocks_per_cu(bool moving, uint32_t accel);
+
+} // namespace rtw

@@ -1,0 +1,273 @@
+// rtw_shim.hip -- extern "C" entry points of librtw_hip.so (include/rtw.h): context, scene upload,
+// blocking render.  Host code only; kernels live in rtw_kernels.hip.  No CPU fallback of any kind:
+// without a HIP device every render entry point fails with RTW_E_NO_DEVICE / RTW_E_HIP.
+#include "rtw_kernels.h"
+#include "rtw_host.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace rtw;
+
+static thread_local int g_last_hip = 0;
+
+#define HIP_TRY(expr)                                                     \
+    do {                                                                  \
+        hipError_t e_ = (expr);                                           \
+        if (e_ != hipSuccess) { g_last_hip = (int)e_; return RTW_E_HIP; } \
+    } while (0)
+
+struct rtw_ctx {
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // scene
+    bool has_scene = false;
+    DevScene sc{};
+    float bg[3] = { 0, 0, 0 };
+    void *d_geom = nullptr, *d_vel = nullptr, *d_mat = nullptr, *d_tex = nullptr, *d_texels = nullptr;
+    DevBvh bvh{};
+    void *d_nodes = nullptr, *d_big_geom = nullptr, *d_big_vel = nullptr, *d_big_index = nullptr;
+    // scratch
+    uint32_t *d_queue = nullptr;
+    unsigned long long *d_stats = nullptr;
+    float *d_out = nullptr;
+    size_t d_out_cap = 0;
+};
+
+template <class T>
+static int upload(void **dst, const std::vector<T> &src) {
+    size_t bytes = src.size() * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIP_TRY(hipMalloc(dst, bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RTW_OK;
+}
+
+extern "C" {
+
+int rtw_abi_version(void) { return RTW_ABI_VERSION; }
+
+int rtw_last_hip_error(void) { return g_last_hip; }
+
+int rtw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *rtw_strerror(int status) {
+    switch (status) {
+    case RTW_OK: return "ok";
+    case RTW_E_INVALID: return "invalid argument";
+    case RTW_E_NO_DEVICE: return "no HIP device";
+    case RTW_E_HIP: return "HIP runtime error";
+    case RTW_E_NOMEM: return "out of memory";
+    case RTW_E_UNSUPPORTED: return "not implemented on the device";
+    case RTW_E_NO_SCENE: return "no scene set";
+    default: return "unknown status";
+    }
+}
+
+int rtw_ctx_create(int device, rtw_ctx **out) {
+    if (!out) return RTW_E_INVALID;
+    *out = nullptr;
+    int n = rtw_device_count();
+    if (n <= 0 || device < 0 || device >= n) return RTW_E_NO_DEVICE;
+    rtw_ctx *c = new (std::nothrow) rtw_ctx();
+    if (!c) return RTW_E_NOMEM;
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) { c->n_cu = prop.multiProcessorCount; e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking); }
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_stats, 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) { g_last_hip = (int)e; rtw_ctx_destroy(c); return RTW_E_HIP; }
+    c->stream = c->own_stream;
+    *out = c;
+    return RTW_OK;
+}
+
+static void free_scene(rtw_ctx *c) {
+    void **bufs[] = { &c->d_geom, &c->d_vel, &c->d_mat, &c->d_tex, &c->d_texels, &c->d_nodes, &c->d_big_geom, &c->d_big_vel, &c->d_big_index };
+    for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    c->has_scene = false;
+}
+
+void rtw_ctx_destroy(rtw_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_scene(c);
+    if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int rtw_ctx_set_stream(rtw_ctx *c, void *hip_stream) {
+    if (!c) return RTW_E_INVALID;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RTW_OK;
+}
+
+int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end) {
+    if (!c || !s || (s->n_spheres && !s->spheres)) return RTW_E_INVALID;
+    if ((s->n_textures && !s->textures) || (s->n_texels && !s->texels)) return RTW_E_INVALID;
+    for (uint32_t i = 0; i < s->n_spheres; i++)
+        if (s->spheres[i].tex >= (int32_t)s->n_textures) return RTW_E_INVALID;
+    for (uint32_t i = 0; i < s->n_textures; i++) {
+        const RtwTexture &t = s->textures[i];
+        if (t.row == 0 || t.col == 0 || (uint64_t)t.texel_offset + (uint64_t)t.row * t.col > s->n_texels) return RTW_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    free_scene(c);
+
+    std::vector<f4> geom(s->n_spheres), vel(s->n_spheres);
+    std::vector<DevMat> mat(s->n_spheres);
+    bool moving = false;
+    for (uint32_t i = 0; i < s->n_spheres; i++) {
+        const RtwSphere &sp = s->spheres[i];
+        geom[i] = f4{ sp.center[0], sp.center[1], sp.center[2], host_mul(sp.radius, sp.radius) };   // sphere.rs:105 radius*radius
+        vel[i] = f4{ sp.velocity[0], sp.velocity[1], sp.velocity[2], 0.0f };
+        if (sp.velocity[0] != 0.0f || sp.velocity[1] != 0.0f || sp.velocity[2] != 0.0f) moving = true;
+        DevMat &m = mat[i];
+        std::memset(&m, 0, sizeof m);
+        for (int k = 0; k < 3; k++) {
+            // tex < 0: (texel * 1.0) * col_mod hoisted (texture.rs:265, sphere.rs:145)
+            m.cm[k] = sp.tex < 0 ? host_mul(host_mul(sp.tex_color[k], 1.0f), sp.col_mod[k]) : sp.col_mod[k];
+            m.emitted[k] = sp.emitted[k];
+        }
+        m.metallicness = sp.metallicness; m.opacity = sp.opacity; m.ir = sp.ir; m.tex = sp.tex;
+    }
+    std::vector<RtwTexture> tex(s->textures, s->textures + s->n_textures);
+    std::vector<float> texels(s->texels, s->texels + 3 * (size_t)s->n_texels);
+
+    int rc;
+    if ((rc = upload(&c->d_geom, geom)) || (rc = upload(&c->d_vel, vel)) || (rc = upload(&c->d_mat, mat)) ||
+        (rc = upload(&c->d_tex, tex)) || (rc = upload(&c->d_texels, texels))) { free_scene(c); return rc; }
+
+    // acceleration structure (Scene::new_sphere builds the AABB tree, viewport.rs:90-105)
+    BvhBuild bb;
+    build_bvh(s->spheres, s->n_spheres, std::fmin(t_begin, t_end), std::fmax(t_begin, t_end), bb);
+    std::vector<f4> big_geom, big_vel;
+    for (uint32_t i : bb.big) { big_geom.push_back(geom[i]); big_vel.push_back(vel[i]); }
+    if ((rc = upload(&c->d_nodes, bb.nodes)) || (rc = upload(&c->d_big_geom, big_geom)) ||
+        (rc = upload(&c->d_big_vel, big_vel)) || (rc = upload(&c->d_big_index, bb.big))) { free_scene(c); return rc; }
+    c->bvh.nodes = (const BvhNode *)c->d_nodes;
+    c->bvh.big_geom = (const f4 *)c->d_big_geom; c->bvh.big_vel = (const f4 *)c->d_big_vel;
+    c->bvh.big_index = (const uint32_t *)c->d_big_index; c->bvh.n_big = (uint32_t)bb.big.size();
+    c->bvh.root = bb.root;
+    c->bvh.cx = bb.centre[0]; c->bvh.cy = bb.centre[1]; c->bvh.cz = bb.centre[2];
+    c->bvh.centre_radius = bb.centre_radius;
+    c->bvh.r_max2 = bb.r_max * bb.r_max * 1.000001f;
+    c->bvh.inv_2rmin = bb.r_min > 0.0f ? 1.0f / (2.0f * bb.r_min) : INFINITY;
+    c->bvh.abs_max = bb.abs_max;
+
+    c->sc.geom = (const f4 *)c->d_geom; c->sc.vel = (const f4 *)c->d_vel; c->sc.mat = (const DevMat *)c->d_mat;
+    c->sc.tex = (const RtwTexture *)c->d_tex; c->sc.texels = (const float *)c->d_texels;
+    c->sc.n = s->n_spheres; c->sc.moving = moving ? 1u : 0u;
+    std::memcpy(c->bg, s->background, sizeof c->bg);
+    c->has_scene = true;
+    return RTW_OK;
+}
+
+int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *out_rgb, RtwStats *stats) {
+    if (!c || !cam || !p || !out_rgb) return RTW_E_INVALID;
+    if (!c->has_scene) return RTW_E_NO_SCENE;
+    if (p->width == 0 || p->height == 0 || p->samples == 0) return RTW_E_INVALID;
+    if (p->integrator > RTW_INTEGRATOR_FLAG || p->sampler > RTW_SAMPLER_NO_RAND || p->accel > RTW_ACCEL_BVH) return RTW_E_INVALID;
+    if (p->part_count > 1 && (p->row_block == 0 || p->part_index >= p->part_count)) return RTW_E_INVALID;
+    if ((uint64_t)p->width * p->height >= (1ull << 32)) return RTW_E_INVALID;
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(c->device));
+
+    KArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.cam = *cam; a.sc = c->sc; a.bvh = c->bvh;
+    a.width = p->width; a.height = p->height;
+    a.n_rows = rtw_part_rows(p->height, p->row_block, p->part_index, p->part_count);
+    a.row_block = p->row_block ? p->row_block : 1; a.part_index = p->part_index; a.part_count = p->part_count;
+    a.tiles_x = (p->width + 7) / 8;
+    const uint64_t total = 64ull * a.tiles_x * ((a.n_rows + 7) / 8);
+    if (total >= (1ull << 32)) return RTW_E_INVALID;
+    a.total_work = (uint32_t)total;
+    a.n_samples = sampler_count(p->sampler, p->samples, &a.s_root);
+    if (a.n_samples == 0) return RTW_E_INVALID;
+    a.sampler = p->sampler; a.integrator = p->integrator; a.depth = p->depth;
+    a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
+    a.inv_gamma = host_div(1.0f, p->gamma);                       // viewport.rs:232
+    a.mint = p->mint; a.maxt = p->maxt;
+    std::memcpy(a.bg, c->bg, sizeof a.bg);
+    a.queue = c->d_queue; a.stats = c->d_stats;
+
+    const size_t out_bytes = (size_t)a.n_rows * p->width * 3 * sizeof(float);
+    hipPointerAttribute_t attr;
+    bool out_on_device = false;
+    if (hipPointerGetAttributes(&attr, out_rgb) == hipSuccess) {
+        out_on_device = attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+    } else (void)hipGetLastError();
+    if (out_on_device) a.out = out_rgb;
+    else {
+        if (c->d_out_cap < out_bytes) {
+            if (c->d_out) (void)hipFree(c->d_out);
+            c->d_out = nullptr; c->d_out_cap = 0;
+            HIP_TRY(hipMalloc((void **)&c->d_out, out_bytes ? out_bytes : 4));
+            c->d_out_cap = out_bytes;
+        }
+        a.out = c->d_out;
+    }
+
+    // persistent grid: as many workgroups as the kernel's registers let be resident, capped by the work
+    uint32_t per_cu = kernel_blocks_per_cu(c->sc.moving != 0, p->accel);
+    uint32_t grid = (uint32_t)c->n_cu * per_cu;
+    const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
+    if (grid > need) grid = need ? need : 1;
+
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 64, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    launch_render(a, c->sc.moving != 0, p->accel, grid, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    unsigned long long h_stats[8];
+    HIP_TRY(hipMemcpyAsync(h_stats, c->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, c->stream));
+    if (!out_on_device) HIP_TRY(hipMemcpyAsync(out_rgb, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->camera_rays = h_stats[0]; stats->segments = h_stats[1];
+        stats->sphere_tests = h_stats[2]; stats->node_tests = h_stats[3];
+        stats->nan_pixels = (uint32_t)h_stats[4]; stats->rows = a.n_rows;
+        stats->kernel_ms = ms;
+        stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RTW_OK;
+}
+
+int rtw_render(const RtwCamera *cam, const RtwScene *scene, const RtwParams *params, float *out_rgb, RtwStats *stats) {
+    if (!cam || !scene || !params) return RTW_E_INVALID;
+    int dev = 0;
+    if (rtw_device_count() <= 0) return RTW_E_NO_DEVICE;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    rtw_ctx *c = nullptr;
+    int rc = rtw_ctx_create(dev, &c);
+    if (rc != RTW_OK) return rc;
+    rc = rtw_ctx_set_scene(c, scene, cam->time0, cam->time0 + cam->shutter);
+    if (rc == RTW_OK) rc = rtw_ctx_render(c, cam, params, out_rgb, stats);
+    rtw_ctx_destroy(c);
+    return rc;
+}
+
+} // extern "C"
