@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (all N): config 3 of BASELINE.json -- the Book-1 final random-spheres scene (485 spheres, scene
+seed 42), 1920 x 1080, 500 spp (render_row sampler), depth 50, gradient sky, render seed 1.  A "step" is
+one full frame: every rank renders its interleaved 8-row blocks into HBM, one RCCL gather puts the frame
+on rank 0.  The frame is a fixed amount of work split over N GPUs, hence "scaling": "strong".
+value = (closest-hit queries == "rays x bounces" of all ranks, counted exactly by the kernel) / wall time.
+
+The JSON line also carries
+  roofline      for the render kernel: ALGORITHMIC f32 flop (DESIGN.md "Roofline": 50/node visit,
+                17/exact sphere test, 120/segment) / mean kernel time (HIP events on the launch stream,
+                taken inside rtw_ctx_render) against the 157.3 TFLOP/s f32 vector peak.  The path is
+                VALU-bound by construction (12 B of HBM per pixel per frame); `hbm` gives the achieved
+                framebuffer GB/s for completeness.
+  cpu_baseline  the CPU oracle (a port: the reference's Rust cannot be built offline) timed on this
+                host's cores on a bounded sample of the SAME frame (every 17th 8-row block, fewer spp).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_NODE, F_SPHERE, F_SEGMENT = 50.0, 17.0, 120.0     # algorithmic f32 flop per unit (DESIGN.md "Roofline")
+PEAK_TFLOPS = 157.3                                 # MI355X f32 vector peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(R, scene, cam, p):
+    """Oracle on the host cores, ~10-20 s, on a subset of the same frame."""
+    import ctypes as C
+    from tests import oracle_binding as O
+    threads = os.cpu_count() or 1
+    q = R.RtwParams.from_buffer_copy(p)
+    q.accel = R.ACCEL_BRUTE                     # the oracle has one closest-hit: the list-order loop
+    q.row_block, q.part_index, q.part_count = 8, 0, 17      # 8 of the 135 row blocks, spread over the frame
+    q.samples = 2
+    _, st = O.render(cam, scene, q, threads)    # calibration
+    rate = st.segments / max(st.total_ms, 1e-3) * 1e3
+    target_s = 12.0
+    q.samples = int(max(2, min(p.samples, round(2 * target_s * rate / max(st.segments, 1)))))
+    _, st = O.render(cam, scene, q, threads)
+    sec = st.total_ms / 1e3
+    return {"value": round(st.segments / sec / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/rtw_oracle.c (f32 restatement of the Rust path, one task per row), rows of every 17th 8-row block "
+                      f"({st.rows} rows) x {q.width} px x {q.samples} spp of the same frame, {st.segments} segments in {sec:.2f} s",
+            "camera_msamples_per_s": round(st.camera_rays / sec / 1e6, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--accel", choices=["bvh", "brute"], default="bvh")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (INVALID as a benchmark; for smoke runs)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import importlib
+    import rtw_amd as R
+    par = importlib.import_module("raytracing-in-a-weekend_amd.parallel")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available() and R.device_count() > 0, "bench.py needs the MI355X: there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene = R.Scene.generate(R.SCENE_C2, 42)
+    cam, p = R.default_view(R.SCENE_C5)          # 1920 x 1080 x 500 spp x depth 50 framing
+    cam.shutter = 0.0                            # config 3 is the static Book-1 scene
+    p.accel = R.ACCEL_BVH if args.accel == "bvh" else R.ACCEL_BRUTE
+    if args.spp:
+        p.samples = args.spp
+    H, W = p.height, p.width
+
+    r = R.Renderer(local_rank)
+    r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
+    local = torch.zeros((par.max_rows(H, world), W, 3), dtype=torch.float32, device=dev)
+
+    def render_rows(row_block, idx, cnt, out):
+        q = R.RtwParams.from_buffer_copy(p)
+        q.row_block, q.part_index, q.part_count = row_block, idx, cnt
+        return r.render(cam, q, out=out.data_ptr())[1]
+
+    def step():
+        frame, st = par.render_frame(render_rows, H, W, rank, world, dev, local=local)
+        return frame, st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    seg = rays = nodes = tests = 0
+    kernel_ms = 0.0
+    frame = None
+    for _ in range(args.steps):
+        frame, st = step()
+        seg += st.segments; rays += st.camera_rays; nodes += st.node_tests; tests += st.sphere_tests
+        kernel_ms += st.kernel_ms
+    fence()
+    elapsed = time.perf_counter() - t0
+    elapsed = par.max_over_ranks(elapsed, world, dev)
+    seg, rays, nodes, tests = par.reduce_counters([seg, rays, nodes, tests], world, dev)
+    kernel_ms_max = par.max_over_ranks(kernel_ms, world, dev)
+
+    if rank == 0:
+        k_s = kernel_ms_max / 1e3 / args.steps                      # mean kernel time per launch (slowest rank)
+        flop = (nodes * F_NODE + tests * F_SPHERE + seg * F_SEGMENT) / args.steps / world   # per launch, per GPU
+        achieved = flop / k_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and world == 1 and not args.spp and args.accel == "bvh":
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Msamples/s (rays x bounces) at 1920x1080x500spp",
+            "value": round(seg / elapsed / 1e6, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Book-1 final random-spheres scene (485 spheres, scene seed 42), "
+                                   f"{W}x{H}, {p.samples} spp (render_row sampler), depth {p.depth}, gradient sky, render seed 1; "
+                                   "rows in interleaved 8-row blocks per GPU + one RCCL gather",
+                       "accel": args.accel, "camera_msamples_per_s": round(rays / elapsed / 1e6, 3),
+                       "segments_per_camera_ray": round(seg / max(rays, 1), 4)},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_TFLOPS, 5), "traffic": traffic,
+                         "kernel": "rtw::render_kernel<moving=false, accel=%s>" % args.accel,
+                         "kernel_ms": round(k_s * 1e3, 3),
+                         "algorithmic_flop_per_launch": flop,
+                         "units_per_launch": {"segments": seg / args.steps / world, "node_visits": nodes / args.steps / world,
+                                              "sphere_tests": tests / args.steps / world},
+                         "hbm": {"achieved": round(H * W * 12 / world / k_s / 1e9, 4), "peak": 8000.0, "unit": "GB/s",
+                                 "note": "framebuffer write only: 12 B/pixel/frame; the path is not HBM-bound"}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(R, scene, cam, p)
+        assert frame is not None and bool(torch.isfinite(frame).all())
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,6 +142,8 @@ typedef struct RtwParams {
 
 #define RTW_FLAG_NONE            0u
 #define RTW_FLAG_RECURSIVE_ORDER 1u  /* oracle only: multiply col_mod in the reference's recursion order */
+#define RTW_FLAG_CPP_DIELECTRIC  2u  /* oracle only: the C++ twin's deterministic dielectric (Schlick term
+                                        commented out, C++/headers/materials.h:106): refract whenever possible */
 
 typedef struct RtwStats {
     uint64_t camera_rays;    /* (pixel, sample) primary rays traced                   */

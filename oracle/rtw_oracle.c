@@ -230,7 +230,7 @@ static inline float reflectance(float cosine, float ref_idx) {
 typedef struct { ray_t next; v3 emitted; float cos_theta; int front_face, cannot_refract; float ratio; } scatter_t;
 
 /* materials.rs:105-154 (+ diffuse :213-228) */
-static scatter_t on_hit(const RtwSphere *s, const hit_t *h, ray_t r, rng_t *rng) {
+static scatter_t on_hit(const RtwSphere *s, const hit_t *h, ray_t r, rng_t *rng, uint32_t flags) {
     scatter_t o; memset(&o, 0, sizeof o);
     o.emitted = v3_ld(s->emitted);
     o.front_face = !(v3_dot(r.dir, h->normal) > 0.0f);
@@ -245,7 +245,9 @@ static scatter_t on_hit(const RtwSphere *s, const hit_t *h, ray_t r, rng_t *rng)
         float refl = reflectance(cos_theta, refraction_ratio);
         v3 direction;
         /* `cannot_refract || reflectance > random()`: xi is drawn only when the first test is false */
-        if (cannot_refract || refl > rng_f32(rng)) direction = v3_reflect(unit_direction, n);
+        int do_reflect = cannot_refract;
+        if (!do_reflect && !(flags & RTW_FLAG_CPP_DIELECTRIC)) do_reflect = refl > rng_f32(rng);
+        if (do_reflect) direction = v3_reflect(unit_direction, n);
         else direction = refract(unit_direction, n, refraction_ratio);
         o.next.origin = h->point; o.next.dir = direction; o.next.time = r.time;
         o.cos_theta = 0.0f; o.cannot_refract = cannot_refract; o.ratio = refraction_ratio;
@@ -300,7 +302,7 @@ static v3 ray_color_gradient_rec(ctx_t *c, ray_t r, uint32_t depth) {
     if (depth < 1) return v3_make(0, 0, 0);
     hit_t h;
     if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
-        scatter_t s = on_hit(&c->sc->spheres[h.sphere], &h, r, c->rng);
+        scatter_t s = on_hit(&c->sc->spheres[h.sphere], &h, r, c->rng, c->p->flags);
         fix_degenerate(&s, &h);
         trace_record(c, 1, &h, &s, r);
         return v3_mul(ray_color_gradient_rec(c, s.next, depth - 1), h.col_mod);
@@ -320,7 +322,7 @@ static v3 ray_color_gradient_iter(ctx_t *c, ray_t r, uint32_t depth) {
             trace_record(c, 0, NULL, NULL, r);
             return v3_mul(sky_gradient(r.dir), thr);
         }
-        scatter_t s = on_hit(&c->sc->spheres[h.sphere], &h, r, c->rng);
+        scatter_t s = on_hit(&c->sc->spheres[h.sphere], &h, r, c->rng, c->p->flags);
         fix_degenerate(&s, &h);
         trace_record(c, 1, &h, &s, r);
         thr = v3_mul(thr, h.col_mod);
@@ -340,7 +342,7 @@ static v3 ray_color_bg_rec(ctx_t *c, ray_t r, uint32_t depth) {
     hit_t h;
     if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
         const RtwSphere *sp = &c->sc->spheres[h.sphere];
-        scatter_t s = on_hit(sp, &h, r, c->rng);
+        scatter_t s = on_hit(sp, &h, r, c->rng, c->p->flags);
         fix_degenerate(&s, &h);
         trace_record(c, 1, &h, &s, r);
         v3 color = v3_mul(ray_color_bg_rec(c, s.next, depth - 1), h.col_mod);
@@ -369,7 +371,7 @@ static v3 ray_color_bg_iter(ctx_t *c, ray_t r, uint32_t depth) {
             goto done;
         }
         const RtwSphere *sp = &c->sc->spheres[h.sphere];
-        scatter_t s = on_hit(sp, &h, r, c->rng);
+        scatter_t s = on_hit(sp, &h, r, c->rng, c->p->flags);
         fix_degenerate(&s, &h);
         trace_record(c, 1, &h, &s, r);
         if (sp->metallicness != 1.0f && !(lambertian_scatter_pdf(s.cos_theta) > 0.0f)) poison = 1;
@@ -407,7 +409,7 @@ static v3 ray_color_flag(ctx_t *c, ray_t r, uint32_t depth) {
             trace_record(c, 1, &h, NULL, r);
             return v3_mul(v3_make(1.0f, 1.0f, 0.0f), thr);
         }
-        scatter_t s = on_hit(sp, &h, r, c->rng);
+        scatter_t s = on_hit(sp, &h, r, c->rng, c->p->flags);
         fix_degenerate(&s, &h);
         trace_record(c, 1, &h, &s, r);
         thr = v3_mul(thr, h.col_mod);

@@ -269,12 +269,14 @@ __global__ __launch_bounds__(RTW_BLOCK) void render_kernel(const KArgs A) {
 
         // ---- 3. one closest-hit query + scatter for every lane that owns a pixel ----------------
         if (have) {
-            int best; float best_t;
-            if (ACCEL == RTW_ACCEL_BVH) closest_bvh<MOVING>(sc, A.bvh, bvh_stack, o, d, tm, A.mint, A.maxt, best, best_t, n_nodes, n_tests);
+            int best = -1; float best_t = 0.0f;
+            const bool no_query = A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL;   // `if depth < 1 { return black }` (ray_color.rs:14-16)
+            if (no_query) {}
+            else if (ACCEL == RTW_ACCEL_BVH) closest_bvh<MOVING>(sc, A.bvh, bvh_stack, o, d, tm, A.mint, A.maxt, best, best_t, n_nodes, n_tests);
             else closest_brute<MOVING>(sc, o, d, tm, A.mint, A.maxt, best, best_t);
-            n_seg++;
             bool finished = false;
-            if (best < 0) {
+            if (no_query) { L = mk(0, 0, 0); finished = true; }
+            else if (n_seg++, best < 0) {
                 v3 miss;
                 if (A.integrator == RTW_INTEGRATOR_BG_COLOR) miss = ld3(A.bg);
                 else if (A.integrator == RTW_INTEGRATOR_FLAG) miss = mk(0.0f, 0.0f, 1.0f);
@@ -320,7 +322,9 @@ __global__ __launch_bounds__(RTW_BLOCK) void render_kernel(const KArgs A) {
                 s++;
                 if (s >= A.n_samples) {
                     v3 col = acc / (float)A.n_samples;           // viewport.rs:301
-                    col = mk(powf(col.x, A.inv_gamma), powf(col.y, A.inv_gamma), powf(col.z, A.inv_gamma));
+                    // gamma_correct (viewport.rs:207-213).  x^1 is x: skipping the libm call keeps the
+                    // gamma == 1 output bit-identical to the CPU (ocml powf is not exact there).
+                    if (A.inv_gamma != 1.0f) col = mk(powf(col.x, A.inv_gamma), powf(col.y, A.inv_gamma), powf(col.z, A.inv_gamma));
                     float *px = A.out + 3 * ((size_t)pk * A.width + pi);
                     px[0] = col.x; px[1] = col.y; px[2] = col.z;
                     if (col.x != col.x || col.y != col.y || col.z != col.z) n_nan++;
