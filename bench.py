@@ -114,12 +114,15 @@ def main():
     fence()
     t0 = time.perf_counter()
     seg = rays = nodes = tests = 0
+    steps3, lanes3 = [0, 0, 0], [0, 0, 0]
     kernel_ms = 0.0
     frame = None
     for _ in range(args.steps):
         frame, st = step()
         seg += st.segments; rays += st.camera_rays; nodes += st.node_tests; tests += st.sphere_tests
         kernel_ms += st.kernel_ms
+        for k in range(3):
+            steps3[k] += st.phase_steps[k]; lanes3[k] += st.phase_lanes[k]
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = par.max_over_ranks(elapsed, world, dev)
@@ -151,6 +154,9 @@ def main():
                          "kernel": "rtw::render_kernel<moving=false, accel=%s>" % args.accel,
                          "kernel_ms": round(k_s * 1e3, 3),
                          "algorithmic_flop_per_launch": flop,
+                         "scheduler_census_rank0": {n: {"wave_steps": steps3[k] // args.steps,
+                                                            "simd_efficiency": round(lanes3[k] / max(1, 64 * steps3[k]), 4)}
+                                                        for k, n in enumerate(("traverse", "leaf", "shade"))},
                          "units_per_launch": {"segments": seg / args.steps / world, "node_visits": nodes / args.steps / world,
                                               "sphere_tests": tests / args.steps / world},
                          "hbm": {"achieved": round(H * W * 12 / world / k_s / 1e9, 4), "peak": 8000.0, "unit": "GB/s",

@@ -25,7 +25,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtw_hip.so")
+LIB_PATH = os.environ.get("RTW_HIP_LIB", os.path.join(_HERE, "librtw_hip.so"))   # override: A/B builds of the same ABI
 
 # ---- enums (include/rtw.h) ---------------------------------------------------------------------
 RTW_OK = 0
@@ -85,10 +85,11 @@ class RtwParams(C.Structure):
 class RtwStats(C.Structure):
     _fields_ = [("camera_rays", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("node_tests", C.c_uint64), ("nan_pixels", C.c_uint32), ("rows", C.c_uint32),
-                ("kernel_ms", C.c_float), ("total_ms", C.c_float)]
+                ("kernel_ms", C.c_float), ("total_ms", C.c_float),
+                ("phase_steps", C.c_uint64 * 3), ("phase_lanes", C.c_uint64 * 3)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k.startswith("phase_") else getattr(self, k)) for k, _ in self._fields_}
 
 
 _lib = None

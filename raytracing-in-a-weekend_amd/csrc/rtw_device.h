@@ -25,7 +25,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // scalar loads (s_load_dwordx4 -> SGPR operands of the VALU ops) instead of 64 identical vector loads.
 typedef const f4 __attribute__((address_space(4))) *cf4_ptr;
 
-struct v3 { float x, y, z; };
+// Member-wise copy on purpose: an implicit (memcpy-style) aggregate copy makes SROA slice the path
+// state into <1 x float> pieces that mem2reg then refuses to promote (24 B of scratch per lane).
+struct v3 {
+    float x, y, z;
+    __device__ __forceinline__ v3() {}
+    __device__ __forceinline__ v3(const v3 &o) : x(o.x), y(o.y), z(o.z) {}
+    __device__ __forceinline__ v3 &operator=(const v3 &o) { x = o.x; y = o.y; z = o.z; return *this; }
+};
 
 __device__ __forceinline__ v3 mk(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ v3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }

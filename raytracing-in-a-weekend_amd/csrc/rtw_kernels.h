@@ -39,7 +39,7 @@ struct KArgs {
     float bg[3];
     float *out;                   // [n_rows][width][3]
     uint32_t *queue;              // work-item counter, zeroed before launch
-    unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels
+    unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels [5..7] phase steps [8..10] phase lanes
 };
 
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream);

@@ -88,7 +88,7 @@ int rtw_ctx_create(int device, rtw_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 64);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_stats, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_stats, 16 * sizeof(unsigned long long));
     if (e != hipSuccess) { g_last_hip = (int)e; rtw_ctx_destroy(c); return RTW_E_HIP; }
     c->stream = c->own_stream;
     *out = c;
@@ -234,12 +234,12 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     if (grid > need) grid = need ? need : 1;
 
     HIP_TRY(hipMemsetAsync(c->d_queue, 0, 64, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     launch_render(a, c->sc.moving != 0, p->accel, grid, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    unsigned long long h_stats[8];
+    unsigned long long h_stats[16];
     HIP_TRY(hipMemcpyAsync(h_stats, c->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, c->stream));
     if (!out_on_device) HIP_TRY(hipMemcpyAsync(out_rgb, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -251,6 +251,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
         stats->sphere_tests = h_stats[2]; stats->node_tests = h_stats[3];
         stats->nan_pixels = (uint32_t)h_stats[4]; stats->rows = a.n_rows;
         stats->kernel_ms = ms;
+        for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return RTW_OK;
