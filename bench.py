@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--accel", choices=["bvh", "brute"], default="bvh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--global-nodes", action="store_true", help="A/B: BVH nodes in global memory (f32) instead of LDS (f16)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (INVALID as a benchmark; for smoke runs)")
     args = ap.parse_args()
 
@@ -86,6 +87,8 @@ def main():
     cam, p = R.default_view(R.SCENE_C5)          # 1920 x 1080 x 500 spp x depth 50 framing
     cam.shutter = 0.0                            # config 3 is the static Book-1 scene
     p.accel = R.ACCEL_BVH if args.accel == "bvh" else R.ACCEL_BRUTE
+    if args.global_nodes:
+        p.flags |= 4          # RTW_FLAG_GLOBAL_NODES
     if args.spp:
         p.samples = args.spp
     H, W = p.height, p.width

@@ -46,7 +46,12 @@ enum {
     RTW_INTEGRATOR_GRADIENT = 0, /* ray_color_gradient, Rust/src/viewport/ray_color.rs:12-41 (== ray_color_d main.rs:17-46) */
     RTW_INTEGRATOR_BG_COLOR = 1, /* ray_color_bg_color, Rust/src/viewport/ray_color.rs:43-92 (emission + background)        */
     RTW_INTEGRATOR_NORMAL   = 2, /* normal shading of the closest hit, C++/src/tests.cpp:76-97 (ray_colorSc)                */
-    RTW_INTEGRATOR_FLAG     = 3  /* RNG-free yellow/blue test integrator, Rust/src/viewport/glass_tests.rs:8-54             */
+    RTW_INTEGRATOR_FLAG     = 3, /* RNG-free yellow/blue test integrator, Rust/src/viewport/glass_tests.rs:8-54             */
+    RTW_INTEGRATOR_RUST2    = 4  /* Rust2 `ray_color` (Rust2/src/viewport/ray_color.rs:12-37): emmited + next * multiplied,
+                                    depth 0 and misses return the background, with Rust2's Material trait objects
+                                    (Rust2/src/objects/material.rs): opacity > 0 -> MirrorGlass{ir}, metallicness == 1 ->
+                                    Mirror (reflects the UN-normalised direction), else Lambertian (unit(n + rand));
+                                    ColorResult{emmited, multiplied} = {emitted, tex * col_mod}                             */
 };
 
 /* ---- samplers: which driver loop generates the camera rays ---------------------------------- */
@@ -142,6 +147,8 @@ typedef struct RtwParams {
 
 #define RTW_FLAG_NONE            0u
 #define RTW_FLAG_RECURSIVE_ORDER 1u  /* oracle only: multiply col_mod in the reference's recursion order */
+#define RTW_FLAG_GLOBAL_NODES    4u  /* device only: keep the BVH nodes in global memory (f32, 64 B) even when the
+                                        f16 LDS-resident copy is available -- for A/B measurements and tests */
 #define RTW_FLAG_CPP_DIELECTRIC  2u  /* oracle only: the C++ twin's deterministic dielectric (Schlick term
                                         commented out, C++/headers/materials.h:106): refract whenever possible */
 
@@ -197,6 +204,11 @@ int rtw_viewport_new(uint32_t width, float aspect_ratio, const float *vfov, cons
 int rtw_viewport_new_from_res(uint32_t width, uint32_t height, const float *vfov, const float *origin,
                               const float *direction, const float *vup, const float *lens_radius,
                               RtwCamera *cam, uint32_t *height_out);
+/* Rust2 `Camera::new(aspect, origin, vup, dir, vfov, lens_radius)` (Rust2/src/viewport/camera.rs:19-53) for
+ * RTW_SAMPLER_CENTRES: pixel00 = left_top, delta_u/delta_v = the FULL-viewport delta_x/delta_y (divided by
+ * width/height at use, Rust2/src/viewport.rs:95-99); the lens offset is the raw disk point (viewport.rs:101). */
+int rtw_camera2_new(float aspect, const float origin[3], const float vup[3], const float dir[3], float vfov,
+                    float lens_radius, RtwCamera *cam);
 /* Sphere::new / new_moving (sphere.rs:151-199): col_mod==NULL -> (1,1,1); mat==NULL -> EMPTY_M. */
 int rtw_sphere_new(const float origin[3], float radius, const float *col_mod,
                    const float *mat3 /* metallicness, opacity, ir */, const float *velocity,
@@ -208,6 +220,24 @@ int rtw_sphere_new_with_texture(const float origin[3], float radius, const float
 uint32_t rtw_part_rows(uint32_t height, uint32_t row_block, uint32_t part_index, uint32_t part_count);
 /* write_img_f32 quantisation: round(clamp(c*255, 0, 255)) (Rust/src/write_img.rs:11-15). */
 void rtw_quantize_u8(const float *rgb, size_t n_values, uint8_t *out);
+/* Rust2 Vec3::to_rgb_u8: round(clamp(c*255.99, 0, 255)) (Rust2/src/vec3.rs:240-246). */
+void rtw_quantize_u8_rust2(const float *rgb, size_t n_values, uint8_t *out);
+
+/* ---- scene wire format and image writers (rtw_io.cpp; host only) -------------------------------- */
+/* The reference's `json` scene object {"spheres":[{origin,radius,col_mod,material{metallicness,opacity,ir},
+ * velocity,texture{row,col,img[]}}]} (Rust/src/viewport.rs:174-205, objects/sphere.rs:44-90,
+ * objects/materials.rs:21-54, texture.rs:28-59; the C++ dialect without velocity/texture is accepted).
+ * rtw_scene_to_json returns the length needed; rtw_scene_from_json uses the count-query pattern
+ * (spheres == NULL -> sizes only). */
+size_t rtw_scene_to_json(const RtwScene *scene, char *buf, size_t cap);
+int rtw_scene_from_json(const char *text, size_t len,
+                        RtwSphere *spheres, uint32_t sphere_cap, uint32_t *n_spheres,
+                        RtwTexture *textures, uint32_t texture_cap, uint32_t *n_textures,
+                        float *texels, uint32_t texel_cap, uint32_t *n_texels);
+/* write_img_f32 (Rust/src/write_img.rs:6-19): quantise and save an 8-bit RGB PNG. */
+int rtw_write_png_f32(const char *path, const float *rgb, uint32_t width, uint32_t height);
+/* write_ppm (C++/src/ppm_writer.cpp:12-27): P3 text with the C++ truncation int(255 c). */
+int rtw_write_ppm_f32(const char *path, const float *rgb, uint32_t width, uint32_t height);
 
 /* Scene generators for the BASELINE configs.  Each fills caller arrays; call with
  * spheres == NULL to query the counts.  Returns RTW_OK or RTW_E_INVALID if capacity is too small. */

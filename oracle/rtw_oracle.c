@@ -15,6 +15,7 @@
  *   Rust/src/viewport/ray_color.rs:12-41  ray_color_gradient -> ray_color_gradient_rec()/path_iterative()
  *   Rust/src/viewport/ray_color.rs:43-92  ray_color_bg_color -> ray_color_bg_rec()
  *   Rust/src/viewport/glass_tests.rs:8-54 test integrator    -> INTEGRATOR_FLAG
+ *   Rust2/src/viewport/ray_color.rs:12-37 + Rust2/src/objects/material.rs:25-162 -> INTEGRATOR_RUST2
  *   Rust/src/objects/sphere.rs:99-147     Sphere::collision_normal -> sphere_hit()
  *   Rust/src/objects/materials.rs:89-154,213-228 Material::on_hit  -> on_hit()
  *   Rust/src/vec3.rs:188-261              Vec3 math + samplers     -> v3_*, random_*()
@@ -418,6 +419,66 @@ static v3 ray_color_flag(ctx_t *c, ray_t r, uint32_t depth) {
     return v3_make(0, 0, 0);
 }
 
+/* ---- Rust2 trait surface ------------------------------------------------------ */
+/* Material::on_hit of Rust2/src/objects/material.rs: Lambertian :25-36, Mirror :75-83, MirrorGlass :130-162.
+ * The hit's ray is the incoming ray (Hit.r), its normal the outward one (Rust2/src/objects/sphere.rs:56-84). */
+static ray_t rust2_on_hit(const RtwSphere *s, const hit_t *h, ray_t r, rng_t *rng, uint32_t flags) {
+    ray_t o; o.origin = h->point; o.time = r.time;
+    if (s->opacity > 0.0f) {                                      /* MirrorGlass{ir}: same arithmetic as the Rust dielectric */
+        int front_face = !(v3_dot(r.dir, h->normal) > 0.0f);
+        v3 n = front_face ? h->normal : v3_neg(h->normal);
+        float refraction_ratio = front_face ? 1.0f / s->ir : s->ir;
+        v3 unit_direction = v3_unit(r.dir);
+        float cos_theta = v3_dot(v3_neg(unit_direction), n);
+        if (cos_theta > 1.0f) cos_theta = 1.0f;
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        int cannot_refract = refraction_ratio * sin_theta > 1.0f;
+        float refl = reflectance(cos_theta, refraction_ratio);
+        int do_reflect = cannot_refract;
+        if (!do_reflect && !(flags & RTW_FLAG_CPP_DIELECTRIC)) do_reflect = refl > rng_f32(rng);
+        o.dir = do_reflect ? v3_reflect(unit_direction, n) : refract(unit_direction, n, refraction_ratio);
+    } else if (s->metallicness == 1.0f) {
+        o.dir = v3_reflect(r.dir, h->normal);                     /* Mirror: h.r.direction.reflect(h.n), not normalised (:80) */
+    } else {
+        o.dir = v3_unit(v3_add(h->normal, random_unit_vec(rng))); /* Lambertian: (h.n + random_unit_vec()).unit() (:28) */
+    }
+    return o;
+}
+
+/* Rust2 ray_color, the reference's recursion (Rust2/src/viewport/ray_color.rs:12-37). */
+static v3 ray_color_rust2_rec(ctx_t *c, ray_t r, uint32_t depth) {
+    if (depth == 0) return v3_ld(c->sc->background);
+    hit_t h;
+    if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
+        const RtwSphere *sp = &c->sc->spheres[h.sphere];
+        ray_t next = rust2_on_hit(sp, &h, r, c->rng, c->p->flags);   /* o.color(&h) draws nothing; o.reflect(&h) does */
+        trace_record(c, 1, &h, NULL, r);
+        v3 next_color = ray_color_rust2_rec(c, next, depth - 1);
+        return v3_add(v3_ld(sp->emitted), v3_mul(next_color, h.col_mod));   /* emmited + next.field_wise_mult(multiplied) */
+    }
+    trace_record(c, 0, NULL, NULL, r);
+    return v3_ld(c->sc->background);
+}
+
+/* Front-to-back form used by the GPU (same paths and draws; sums/products associate differently). */
+static v3 ray_color_rust2_iter(ctx_t *c, ray_t r, uint32_t depth) {
+    v3 thr = v3_make(1.0f, 1.0f, 1.0f), L = v3_make(0, 0, 0);
+    for (uint32_t k = 0; k < depth; k++) {
+        hit_t h;
+        if (!closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
+            trace_record(c, 0, NULL, NULL, r);
+            return v3_add(L, v3_mul(v3_ld(c->sc->background), thr));
+        }
+        const RtwSphere *sp = &c->sc->spheres[h.sphere];
+        ray_t next = rust2_on_hit(sp, &h, r, c->rng, c->p->flags);
+        trace_record(c, 1, &h, NULL, r);
+        L = v3_add(L, v3_mul(v3_ld(sp->emitted), thr));
+        thr = v3_mul(thr, h.col_mod);
+        r = next;
+    }
+    return v3_add(L, v3_mul(v3_ld(c->sc->background), thr));        /* depth == 0 returns the background */
+}
+
 static v3 ray_color(ctx_t *c, ray_t r) {
     const RtwParams *p = c->p;
     int rec = (p->flags & RTW_FLAG_RECURSIVE_ORDER) != 0;
@@ -425,6 +486,7 @@ static v3 ray_color(ctx_t *c, ray_t r) {
     case RTW_INTEGRATOR_GRADIENT: return rec ? ray_color_gradient_rec(c, r, p->depth) : ray_color_gradient_iter(c, r, p->depth);
     case RTW_INTEGRATOR_BG_COLOR: return rec ? ray_color_bg_rec(c, r, p->depth) : ray_color_bg_iter(c, r, p->depth);
     case RTW_INTEGRATOR_NORMAL:   return ray_color_normal(c, r);
+    case RTW_INTEGRATOR_RUST2:    return rec ? ray_color_rust2_rec(c, r, p->depth) : ray_color_rust2_iter(c, r, p->depth);
     default:                      return ray_color_flag(c, r, p->depth);
     }
 }
@@ -533,7 +595,7 @@ static int params_ok(const RtwCamera *cam, const RtwScene *sc, const RtwParams *
     if (!cam || !sc || !p) return 0;
     if (p->width == 0 || p->height == 0 || p->samples == 0) return 0;
     if (sc->n_spheres && !sc->spheres) return 0;
-    if (p->integrator > RTW_INTEGRATOR_FLAG || p->sampler > RTW_SAMPLER_NO_RAND) return 0;
+    if (p->integrator > RTW_INTEGRATOR_RUST2 || p->sampler > RTW_SAMPLER_NO_RAND) return 0;
     if (p->part_count > 1 && (p->row_block == 0 || p->part_index >= p->part_count)) return 0;
     return 1;
 }

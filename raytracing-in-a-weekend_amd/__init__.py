@@ -29,10 +29,10 @@ LIB_PATH = os.environ.get("RTW_HIP_LIB", os.path.join(_HERE, "librtw_hip.so"))  
 
 # ---- enums (include/rtw.h) ---------------------------------------------------------------------
 RTW_OK = 0
-INTEGRATOR_GRADIENT, INTEGRATOR_BG_COLOR, INTEGRATOR_NORMAL, INTEGRATOR_FLAG = 0, 1, 2, 3
+INTEGRATOR_GRADIENT, INTEGRATOR_BG_COLOR, INTEGRATOR_NORMAL, INTEGRATOR_FLAG, INTEGRATOR_RUST2 = 0, 1, 2, 3, 4
 SAMPLER_ROW, SAMPLER_STRATIFIED, SAMPLER_CENTRES, SAMPLER_NO_RAND = 0, 1, 2, 3
 ACCEL_BRUTE, ACCEL_BVH = 0, 1
-FLAG_RECURSIVE_ORDER = 1
+FLAG_RECURSIVE_ORDER, FLAG_CPP_DIELECTRIC, FLAG_GLOBAL_NODES = 1, 2, 4
 SCENE_C1, SCENE_C2, SCENE_C4, SCENE_C5, SCENE_METAL_TEST = 1, 2, 4, 5, 6
 
 # materials.rs:157-212 presets as (metallicness, opacity, ir)
@@ -125,6 +125,15 @@ def lib() -> C.CDLL:
     L.rtw_part_rows.argtypes = [C.c_uint32] * 4
     L.rtw_quantize_u8.restype = None
     L.rtw_quantize_u8.argtypes = [fp, C.c_size_t, C.POINTER(C.c_uint8)]
+    L.rtw_camera2_new.argtypes = [C.c_float, fp, fp, fp, C.c_float, C.c_float, C.POINTER(RtwCamera)]
+    L.rtw_quantize_u8_rust2.restype = None
+    L.rtw_quantize_u8_rust2.argtypes = [fp, C.c_size_t, C.POINTER(C.c_uint8)]
+    L.rtw_scene_to_json.restype = C.c_size_t
+    L.rtw_scene_to_json.argtypes = [C.POINTER(RtwScene), C.c_char_p, C.c_size_t]
+    L.rtw_scene_from_json.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(RtwSphere), C.c_uint32, C.POINTER(C.c_uint32),
+                                      C.POINTER(RtwTexture), C.c_uint32, C.POINTER(C.c_uint32), fp, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.rtw_write_png_f32.argtypes = [C.c_char_p, fp, C.c_uint32, C.c_uint32]
+    L.rtw_write_ppm_f32.argtypes = [C.c_char_p, fp, C.c_uint32, C.c_uint32]
     L.rtw_scene_generate.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(RtwSphere), C.c_uint32, C.POINTER(C.c_uint32),
                                      C.POINTER(RtwTexture), C.c_uint32, C.POINTER(C.c_uint32),
                                      fp, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -224,6 +233,36 @@ class Scene:
     def new_sphere(spheres: Sequence) -> "Scene":
         return Scene(spheres)
 
+    def to_json(self) -> str:
+        """`Into<JsonValue> for Scene` (Rust/src/viewport.rs:174-180)."""
+        n = lib().rtw_scene_to_json(C.byref(self.pod), None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().rtw_scene_to_json(C.byref(self.pod), buf, n + 1)
+        return buf.value.decode()
+
+    @staticmethod
+    def from_json(text: str) -> "Scene":
+        """`TryFrom<JsonValue> for Scene` (Rust/src/viewport.rs:181-205); raises RtwError like ParseError."""
+        L = lib()
+        raw = text.encode()
+        ns, nt, nx = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(L.rtw_scene_from_json(raw, len(raw), None, 0, C.byref(ns), None, 0, C.byref(nt), None, 0, C.byref(nx)), "rtw_scene_from_json")
+        sp = (RtwSphere * max(1, ns.value))()
+        tx = (RtwTexture * max(1, nt.value))()
+        tl = np.zeros((max(1, nx.value), 3), np.float32)
+        _check(L.rtw_scene_from_json(raw, len(raw), sp, ns.value, C.byref(ns), tx, nt.value, C.byref(nt),
+                                     tl.ctypes.data_as(C.POINTER(C.c_float)), nx.value, C.byref(nx)), "rtw_scene_from_json")
+        return Scene._from_arrays(sp, ns.value, tx, nt.value, tl, nx.value)
+
+    @staticmethod
+    def _from_arrays(sp, ns, tx, nt, tl, nx) -> "Scene":
+        sc = Scene(list(sp)[:ns])
+        sc._textures, sc.n_textures, sc._texels, sc.n_texels = tx, nt, tl, nx
+        sc.pod.textures = C.cast(tx, C.POINTER(RtwTexture))
+        sc.pod.texels = tl.ctypes.data_as(C.POINTER(C.c_float))
+        sc.pod.n_textures, sc.pod.n_texels = nt, nx
+        return sc
+
     @staticmethod
     def generate(which: int, scene_seed: int = 42) -> "Scene":
         """One of the BASELINE config scenes, laid out by the C++ host library."""
@@ -235,12 +274,7 @@ class Scene:
         tl = np.zeros((max(1, nx.value), 3), np.float32)
         _check(L.rtw_scene_generate(which, scene_seed, sp, ns.value, C.byref(ns), tx, nt.value, C.byref(nt),
                                     tl.ctypes.data_as(C.POINTER(C.c_float)), nx.value, C.byref(nx)), "rtw_scene_generate")
-        sc = Scene(list(sp)[: ns.value])
-        sc._textures, sc.n_textures, sc._texels, sc.n_texels = tx, nt.value, tl, nx.value
-        sc.pod.textures = C.cast(tx, C.POINTER(RtwTexture))
-        sc.pod.texels = tl.ctypes.data_as(C.POINTER(C.c_float))
-        sc.pod.n_textures, sc.pod.n_texels = nt.value, nx.value
-        return sc
+        return Scene._from_arrays(sp, ns.value, tx, nt.value, tl, nx.value)
 
 
 class Viewport:
@@ -292,6 +326,21 @@ class Viewport:
     def async_render(self, ray_color: int, scene: Scene, device: int = 0, accel: int = ACCEL_BVH) -> np.ndarray:
         """async_render / render_row (viewport.rs:215-305): exactly `samples` rays, shutter time."""
         return self._render(ray_color, SAMPLER_ROW, scene, device, accel)
+
+    def render_multi(self, ray_color: int, scene: Scene, device: int = 0, accel: int = ACCEL_BVH):
+        """render_multi (viewport.rs:249-269): frames start_frame .. start_frame + number_of_frames, each rendered
+        with time = frame / fps (the scene and its time-expanded BVH are uploaded once for the whole clip)."""
+        start = getattr(self, "start_frame", 0)
+        count = getattr(self, "number_of_frames", 1)
+        video = []
+        with Renderer(device) as r:
+            t0 = float(np.float32(start) / np.float32(self.fps))
+            t1 = float(np.float32(start + max(count, 1) - 1) / np.float32(self.fps)) + float(self.shutter_speed)
+            r.set_scene(scene, t0, t1)
+            for frame in range(start, start + count):
+                self.frame = frame
+                video.append(r.render(self.camera(), self.params(ray_color, SAMPLER_ROW, accel))[0])
+        return video
 
     def render_no_rand(self, ray_color: int, scene: Scene, device: int = 0, accel: int = ACCEL_BVH) -> np.ndarray:
         return self._render(ray_color, SAMPLER_NO_RAND, scene, device, accel)
@@ -364,6 +413,33 @@ def quantize_u8(img: np.ndarray) -> np.ndarray:
     out = np.empty(a.shape, np.uint8)
     lib().rtw_quantize_u8(a.ctypes.data_as(C.POINTER(C.c_float)), a.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out
+
+
+def camera2_new(aspect, origin, vup, direction, vfov, lens_radius) -> RtwCamera:
+    """Rust2 `Camera::new` (Rust2/src/viewport/camera.rs:19-53), for SAMPLER_CENTRES."""
+    cam = RtwCamera()
+    _check(lib().rtw_camera2_new(float(aspect), _fptr(_f3(origin)), _fptr(_f3(vup)), _fptr(_f3(direction)), float(vfov),
+                                 float(lens_radius), C.byref(cam)), "rtw_camera2_new")
+    return cam
+
+
+def quantize_u8_rust2(img: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(img, np.float32)
+    out = np.empty(a.shape, np.uint8)
+    lib().rtw_quantize_u8_rust2(a.ctypes.data_as(C.POINTER(C.c_float)), a.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def write_img_f32(img: np.ndarray, filename: str):
+    """write_img_f32 (Rust/src/write_img.rs:6-19): 8-bit RGB PNG."""
+    a = np.ascontiguousarray(img, np.float32)
+    _check(lib().rtw_write_png_f32(filename.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0]), "rtw_write_png_f32")
+
+
+def write_ppm(filename: str, img: np.ndarray):
+    """write_ppm (C++/src/ppm_writer.cpp:3-27): P3 text."""
+    a = np.ascontiguousarray(img, np.float32)
+    _check(lib().rtw_write_ppm_f32(filename.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0]), "rtw_write_ppm_f32")
 
 
 def device_count() -> int:

@@ -162,30 +162,55 @@ __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
 // Material::on_hit (materials.rs:105-154) followed by the degenerate-direction fix-up of
 // ray_color_* (ray_color.rs:31-33).  Returns the next direction; cos_theta for bg_color.
 __device__ __forceinline__ v3 on_hit(const DevMat &m, v3 normal, v3 dir, Rng &rng, float &cos_theta) {
-    bool front = !(dot(dir, normal) > 0.0f);
+    const bool front = !(dot(dir, normal) > 0.0f);
+    // Shared by both branches: unit(dir), and its mirror direction.  reflect(ud, -n) == reflect(ud, n)
+    // bit for bit ((-n*2) * dot(ud,-n) == (n*2) * dot(ud,n): negation is exact and commutes with the
+    // rounded products and sums), so the dielectric's reflect about the ray-facing normal is this too.
+    const v3 ud = unit(dir);
+    const v3 refl = reflect(ud, normal);
     v3 next;
     if (m.opacity > 0.0f) {
-        v3 n = front ? normal : -normal;
-        float ratio = front ? 1.0f / m.ir : m.ir;
-        v3 ud = unit(dir);
+        const v3 n = front ? normal : -normal;
+        const float ratio = front ? 1.0f / m.ir : m.ir;
         float ct = dot(-ud, n);
         if (ct > 1.0f) ct = 1.0f;
-        float st = __builtin_sqrtf(1.0f - ct * ct);
-        bool cannot_refract = ratio * st > 1.0f;
-        float refl = reflectance(ct, ratio);
+        const float st = __builtin_sqrtf(1.0f - ct * ct);
+        const bool cannot_refract = ratio * st > 1.0f;
+        const float rfl = reflectance(ct, ratio);
         bool do_reflect = cannot_refract;
-        if (!do_reflect) do_reflect = refl > rng_f32(rng);   // xi drawn only when refraction is possible
-        next = do_reflect ? reflect(ud, n) : refract(ud, n, ratio);
+        if (!do_reflect) do_reflect = rfl > rng_f32(rng);   // xi drawn only when refraction is possible
+        next = do_reflect ? refl : refract(ud, n, ratio);
         cos_theta = 0.0f;
     } else {
-        v3 target = normal + random_unit_vec(rng);            // drawn even for mirrors (materials.rs:142)
-        v3 sc = close_to_zero(target) ? normal : target;
-        v3 refl = reflect(unit(dir), normal);
+        const v3 target = normal + random_unit_vec(rng);      // drawn even for mirrors (materials.rs:142)
+        const v3 sc = close_to_zero(target) ? normal : target;
         next = refl * m.metallicness + sc * (1.0f - m.metallicness);
         cos_theta = (m.metallicness != 1.0f) ? dot(sc, normal) : 0.0f;
     }
     if (close_to_zero(next)) next = front ? normal : normal * -1.0f;
     return next;
+}
+
+// Rust2's Material trait objects (Rust2/src/objects/material.rs): MirrorGlass :130-162 (the Rust
+// dielectric's arithmetic), Mirror :75-83 (reflects the un-normalised direction), Lambertian :25-36
+// (unit(n + random_unit_vec())).  No degenerate-direction fix-up in Rust2's ray_color.
+__device__ __forceinline__ v3 on_hit_rust2(const DevMat &m, v3 normal, v3 dir, Rng &rng) {
+    if (m.opacity > 0.0f) {
+        const bool front = !(dot(dir, normal) > 0.0f);
+        const v3 n = front ? normal : -normal;
+        const float ratio = front ? 1.0f / m.ir : m.ir;
+        const v3 ud = unit(dir);
+        float ct = dot(-ud, n);
+        if (ct > 1.0f) ct = 1.0f;
+        const float st = __builtin_sqrtf(1.0f - ct * ct);
+        const bool cannot_refract = ratio * st > 1.0f;
+        const float rfl = reflectance(ct, ratio);
+        bool do_reflect = cannot_refract;
+        if (!do_reflect) do_reflect = rfl > rng_f32(rng);
+        return do_reflect ? reflect(ud, n) : refract(ud, n, ratio);
+    }
+    if (m.metallicness == 1.0f) return reflect(dir, normal);
+    return unit(normal + random_unit_vec(rng));
 }
 
 // ray_color.rs:38-40

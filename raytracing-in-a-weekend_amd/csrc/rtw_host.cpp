@@ -104,6 +104,35 @@ void rtw_quantize_u8(const float *rgb, size_t n, uint8_t *out) {
     }
 }
 
+void rtw_quantize_u8_rust2(const float *rgb, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        float v = rgb[i] * 255.99f;                     // Rust2/src/vec3.rs:240-246
+        v = v != v ? v : (v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));
+        v = std::round(v);
+        out[i] = v != v ? 0 : (uint8_t)v;
+    }
+}
+
+// Rust2 Camera::new (Rust2/src/viewport/camera.rs:19-53)
+int rtw_camera2_new(float aspect, const float origin[3], const float vup[3], const float dir[3], float vfov,
+                    float lens_radius, RtwCamera *cam) {
+    if (!cam || !origin || !vup || !dir) return RTW_E_INVALID;
+    V w = -ld(dir);
+    V u = unit(cross(ld(vup), w));
+    V v = cross(w, u);
+    float h = std::tan(vfov * 3.14159265358979323846f / 360.0f);
+    float viewport_height = 2.0f * h;
+    float viewport_width = aspect * viewport_height;
+    V viewport_u = u * viewport_width;
+    V viewport_v = (-v) * viewport_height;
+    std::memset(cam, 0, sizeof *cam);
+    st(cam->origin, ld(origin)); st(cam->u, u); st(cam->v, v);
+    st(cam->pixel00, ((-w) - viewport_u / 2.0f) - viewport_v / 2.0f);    // left_top
+    st(cam->delta_u, viewport_u); st(cam->delta_v, viewport_v);          // delta_x, delta_y
+    cam->lens_radius = lens_radius;
+    return RTW_OK;
+}
+
 // Viewport::new (viewport.rs:308-401)
 int rtw_viewport_new(uint32_t width, float aspect_ratio, const float *vfov, const float *origin,
                      const float *direction, const float *vup, const float *lens_radius,
@@ -390,8 +419,24 @@ struct Builder {
 
 } // namespace
 
+namespace {
+// f32 -> f16 bits with directed rounding (value must be finite and within the f16 range)
+uint16_t half_bits(float f, bool up) {
+    _Float16 h = (_Float16)f;                 // round to nearest even
+    uint16_t b; std::memcpy(&b, &h, 2);
+    const float back = (float)h;
+    if (up ? back < f : back > f) {           // step one ulp toward the requested direction
+        if (b == 0x8000u) b = 0;              // -0 -> +0 before stepping
+        const bool neg = (b & 0x8000u) != 0;
+        if (up) b = neg ? (uint16_t)(b - 1) : (uint16_t)(b + 1);
+        else    b = neg ? (uint16_t)(b + 1) : (b == 0 ? (uint16_t)0x8001u : (uint16_t)(b - 1));
+    }
+    return b;
+}
+} // namespace
+
 void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end, BvhBuild &out) {
-    out.nodes.clear(); out.big.clear();
+    out.nodes.clear(); out.nodes16.clear(); out.big.clear();
     out.root = std::numeric_limits<int32_t>::min();
     out.centre[0] = out.centre[1] = out.centre[2] = 0.0f;
     out.centre_radius = 0.0f; out.r_min = 0.0f; out.r_max = 0.0f; out.abs_max = 0.0f; out.depth = 0;
@@ -451,6 +496,20 @@ void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end,
     }
     out.centre_radius = (float)(std::sqrt(r2) * 1.000001);
     out.r_min = rmin; out.r_max = rmax;
+
+    // f16 copy for the LDS-resident traversal: only when it fits and every coordinate is far inside the
+    // f16 range (outward rounding then costs <= 2^-11 relative per plane)
+    if (!out.nodes.empty() && out.nodes.size() <= RTW_LDS_NODES_MAX && n < 32768u && out.abs_max < 30000.0f) {
+        out.nodes16.resize(out.nodes.size());
+        for (size_t i = 0; i < out.nodes.size(); i++) {
+            const BvhNode &a = out.nodes[i]; BvhNode16 &b = out.nodes16[i];
+            for (int k = 0; k < 3; k++) {
+                b.lo0[k] = half_bits(a.lo0[k], false); b.hi0[k] = half_bits(a.hi0[k], true);
+                b.lo1[k] = half_bits(a.lo1[k], false); b.hi1[k] = half_bits(a.hi1[k], true);
+            }
+            b.c0 = (int16_t)a.c0; b.c1 = (int16_t)a.c1; b.pad = 0;
+        }
+    }
 }
 
 } // namespace rtw

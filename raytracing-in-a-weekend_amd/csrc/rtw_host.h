@@ -25,11 +25,23 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
+// Compact node for the LDS-resident variant: the same two child boxes as f16, rounded OUTWARD (lo down,
+// hi up: the tree only prunes, so larger boxes stay conservative), 16-bit child ids.  32 bytes.
+struct BvhNode16 {
+    uint16_t lo0[3], hi0[3];
+    uint16_t lo1[3], hi1[3];
+    int16_t c0, c1;
+    uint32_t pad;
+};
+static_assert(sizeof(BvhNode16) == 32, "BvhNode16 must be 32 bytes");
+#define RTW_LDS_NODES_MAX 512 // inner nodes the LDS variant holds (16 KB)
+
 #define RTW_MAX_BIG 16        // spheres far larger than the rest are tested exactly, outside the tree
 #define RTW_BVH_STACK 32      // builder guarantees depth <= RTW_BVH_STACK
 
 struct BvhBuild {
     std::vector<BvhNode> nodes;          // nodes[0] is the root (absent when < 2 tree spheres)
+    std::vector<BvhNode16> nodes16;      // f16 copy, filled only when it is usable (see build_bvh)
     std::vector<uint32_t> big;           // sphere indices tested by the uniform pre-pass
     int32_t root;                        // node index, or ~sphere for a single tree sphere, or INT32_MIN if empty
     // per-ray padding constants (DESIGN.md "Conservative traversal"): over the TREE spheres only

@@ -10,6 +10,8 @@ namespace rtw {
 // Device view of the acceleration structure built by build_bvh() (rtw_host.cpp).
 struct DevBvh {
     const BvhNode *nodes;
+    const BvhNode16 *nodes16;     // f16 copy for the LDS-resident variant, or null
+    uint32_t n_nodes;
     const f4 *big_geom;           // {cx, cy, cz, r*r} of the spheres kept outside the tree
     const f4 *big_vel;
     const uint32_t *big_index;    // their indices in the scene list
@@ -42,8 +44,9 @@ struct KArgs {
     unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels [5..7] phase steps [8..10] phase lanes
 };
 
+// accel: RTW_ACCEL_BRUTE, RTW_ACCEL_BVH; the BVH launch picks the LDS-resident variant when a.bvh.nodes16 != null
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream);
 // Resident workgroups per CU for the kernel variant (occupancy API), >= 1.
-uint32_t kernel_blocks_per_cu(bool moving, uint32_t accel);
+uint32_t kernel_blocks_per_cu(bool moving, uint32_t accel, bool lds_nodes);
 
 } // namespace rtw

@@ -23,6 +23,7 @@
 //   (ballot + popcount), the other lanes keep their state (traversal stack in LDS) and wait.  That
 //   turns three nested divergent loops into one loop whose body runs with most lanes live.
 #include "rtw_kernels.h"
+#include <type_traits>
 
 namespace rtw {
 
@@ -119,7 +120,7 @@ __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float 
     const DevScene &sc = A.sc;
     if (best < 0) {
         v3 miss;
-        if (A.integrator == RTW_INTEGRATOR_BG_COLOR) miss = ld3(A.bg);
+        if (A.integrator == RTW_INTEGRATOR_BG_COLOR || A.integrator == RTW_INTEGRATOR_RUST2) miss = ld3(A.bg);
         else if (A.integrator == RTW_INTEGRATOR_FLAG) miss = mk(0.0f, 0.0f, 1.0f);
         else miss = sky_gradient(pt.d);
         pt.L = pt.L + miss * pt.thr;
@@ -140,6 +141,15 @@ __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float 
         return true;
     }
     const v3 cm = sphere_albedo(sc, mat, normal);
+    if (A.integrator == RTW_INTEGRATOR_RUST2) {              // Rust2/src/viewport/ray_color.rs:17-31, front-to-back
+        const v3 nd2 = on_hit_rust2(mat, normal, pt.d, pt.rng);
+        pt.L = pt.L + ld3(mat.emitted) * pt.thr;
+        pt.thr = pt.thr * cm;
+        pt.o = point; pt.d = nd2;
+        pt.k++;
+        if (pt.k >= A.depth) { pt.L = pt.L + ld3(A.bg) * pt.thr; return true; }   // depth 0 returns bg_color
+        return false;
+    }
     float cos_theta;
     const v3 nd = on_hit(mat, normal, pt.d, pt.rng, cos_theta);
     if (A.integrator == RTW_INTEGRATOR_BG_COLOR) {           // ray_color.rs:64-88, front-to-back
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
         if (have) {
             bool finished;
             if (A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
-                pt.L = mk(0, 0, 0); finished = true;
+                pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0); finished = true;
             } else {
                 int best; float best_t;
                 closest_brute<MOVING>(A.sc, pt.o, pt.d, pt.tm, A.mint, A.maxt, best, best_t);
@@ -359,11 +369,57 @@ __device__ __forceinline__ int trav_begin(const KArgs &A, const Path &pt, Trav &
 }
 
 // After a node/leaf step: take the next entry off the stack (or finish).
-__device__ __forceinline__ int trav_pop(Trav &tr, const int *stack) {
+template <class S>
+__device__ __forceinline__ int trav_pop(Trav &tr, const S *stack) {
     if (tr.sp == 0) return PH_SHADE;
     tr.sp--;
-    tr.node = stack[tr.sp * RTW_BLOCK + threadIdx.x];
+    tr.node = (int)stack[tr.sp * RTW_BLOCK + threadIdx.x];
     return tr.node < 0 ? PH_LEAF : PH_TRAV;
+}
+
+// Both slab results are in: descend into the nearer child, push the farther (or pop).
+template <class S>
+__device__ __forceinline__ int trav_descend(Trav &tr, S *stack, float e0, float x0, float e1, float x1, int c0, int c1) {
+    const bool h0 = e0 <= x0 && x0 >= tr.lo_lim && e0 <= tr.hi_lim;
+    const bool h1 = e1 <= x1 && x1 >= tr.lo_lim && e1 <= tr.hi_lim;
+    if (h0 && h1) {
+        const bool near0 = e0 <= e1;
+        stack[tr.sp * RTW_BLOCK + threadIdx.x] = (S)(near0 ? c1 : c0);
+        tr.sp++;
+        tr.node = near0 ? c0 : c1;
+        return tr.node < 0 ? PH_LEAF : PH_TRAV;
+    }
+    if (h0) { tr.node = c0; return c0 < 0 ? PH_LEAF : PH_TRAV; }
+    if (h1) { tr.node = c1; return c1 < 0 ? PH_LEAF : PH_TRAV; }
+    return trav_pop(tr, stack);
+}
+
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+// f16 halves of a dword as f32 (scalar casts only: element access through f16 ext-vectors is miscompiled
+// by this toolchain -- lanes came back undefined)
+__device__ __forceinline__ float h_lo(unsigned int w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)); }
+__device__ __forceinline__ float h_hi(unsigned int w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+
+// One inner-node visit, nodes resident in LDS as f16 (BvhNode16): two ds_read_b128 instead of four
+// global loads; the f16 planes feed v_fma_mix_f32 directly.
+__device__ __forceinline__ int trav_node_lds(const u4 *lnodes, Trav &tr, short *stack) {
+    const u4 r0 = lnodes[tr.node * 2], r1 = lnodes[tr.node * 2 + 1];
+    // r0 = {lo0.x lo0.y} {lo0.z hi0.x} {hi0.y hi0.z} {lo1.x lo1.y}   r1 = {lo1.z hi1.x} {hi1.y hi1.z} {c0 c1} pad
+    const int c0 = (int)(short)(r1.z & 0xFFFFu), c1 = (int)(short)(r1.z >> 16);
+    float t1, t2;
+    t1 = __builtin_fmaf(h_lo(r0.x), tr.ix, tr.kpx); t2 = __builtin_fmaf(h_hi(r0.y), tr.ix, tr.kmx);
+    float e0 = fminf(t1, t2), x0 = fmaxf(t1, t2);
+    t1 = __builtin_fmaf(h_hi(r0.x), tr.iy, tr.kpy); t2 = __builtin_fmaf(h_lo(r0.z), tr.iy, tr.kmy);
+    e0 = fmaxf(e0, fminf(t1, t2)); x0 = fminf(x0, fmaxf(t1, t2));
+    t1 = __builtin_fmaf(h_lo(r0.y), tr.iz, tr.kpz); t2 = __builtin_fmaf(h_hi(r0.z), tr.iz, tr.kmz);
+    e0 = fmaxf(e0, fminf(t1, t2)); x0 = fminf(x0, fmaxf(t1, t2));
+    t1 = __builtin_fmaf(h_lo(r0.w), tr.ix, tr.kpx); t2 = __builtin_fmaf(h_hi(r1.x), tr.ix, tr.kmx);
+    float e1 = fminf(t1, t2), x1 = fmaxf(t1, t2);
+    t1 = __builtin_fmaf(h_hi(r0.w), tr.iy, tr.kpy); t2 = __builtin_fmaf(h_lo(r1.y), tr.iy, tr.kmy);
+    e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
+    t1 = __builtin_fmaf(h_lo(r1.x), tr.iz, tr.kpz); t2 = __builtin_fmaf(h_hi(r1.y), tr.iz, tr.kmz);
+    e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
+    return trav_descend(tr, stack, e0, x0, e1, x1, c0, c1);
 }
 
 // One inner-node visit: two slab tests, descend into the nearer child, push the farther.
@@ -385,28 +441,25 @@ __device__ __forceinline__ int trav_node(const DevBvh &bv, Trav &tr, int *stack)
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
     t1 = __builtin_fmaf(n2.x, tr.iz, tr.kpz); t2 = __builtin_fmaf(n2.w, tr.iz, tr.kmz);
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
-    const bool h0 = e0 <= x0 && x0 >= tr.lo_lim && e0 <= tr.hi_lim;
-    const bool h1 = e1 <= x1 && x1 >= tr.lo_lim && e1 <= tr.hi_lim;
-    if (h0 && h1) {
-        const bool near0 = e0 <= e1;
-        stack[tr.sp * RTW_BLOCK + threadIdx.x] = near0 ? c1 : c0;
-        tr.sp++;
-        tr.node = near0 ? c0 : c1;
-        return tr.node < 0 ? PH_LEAF : PH_TRAV;
-    }
-    if (h0) { tr.node = c0; return c0 < 0 ? PH_LEAF : PH_TRAV; }
-    if (h1) { tr.node = c1; return c1 < 0 ? PH_LEAF : PH_TRAV; }
-    return trav_pop(tr, stack);
+    return trav_descend(tr, stack, e0, x0, e1, x1, c0, c1);
 }
 
 #ifndef RTW_BVH_WAVES
 #define RTW_BVH_WAVES 5        /* min waves per SIMD the register allocator must leave room for */
 #endif
-template <bool MOVING>
+template <bool MOVING, bool LDSN>
 __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KArgs A) {
-    // per-lane traversal stack, [level][thread]: a level is one conflict-free LDS row
-    __shared__ int stack[RTW_BVH_STACK * RTW_BLOCK];
+    // per-lane traversal stack, [level][thread]: a level is one conflict-free LDS row.  The LDS-node
+    // variant has <= 512 nodes and < 32768 spheres, so its entries fit 16 bits: 16 KB stack + 16 KB nodes.
+    typedef typename std::conditional<LDSN, short, int>::type stack_t;
+    __shared__ stack_t stack[RTW_BVH_STACK * RTW_BLOCK];
+    __shared__ u4 lnodes[LDSN ? RTW_LDS_NODES_MAX * 2 : 1];
     const DevScene &sc = A.sc;
+    if (LDSN) {
+        const u4 *src = (const u4 *)A.bvh.nodes16;
+        for (uint32_t i = threadIdx.x; i < A.bvh.n_nodes * 2u; i += RTW_BLOCK) lnodes[i] = src[i];
+        __syncthreads();
+    }
 
     int ph = PH_SHADE;
     bool have = false, inflight = false, newpath = false;
@@ -417,6 +470,9 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
     uint32_t n_seg = 0, n_rays = 0, n_nan = 0, n_nodes = 0, n_tests = 0;
     uint32_t c_steps[3] = { 0, 0, 0 };              // wave-uniform (SGPR) census of the scheduler
     unsigned long long c_lanes[3] = { 0, 0, 0 };
+#ifdef RTW_STAMP
+    unsigned long long c_time[3] = { 0, 0, 0 };
+#endif
 
     for (;;) {
         // ---- scheduler: run the phase most lanes are waiting for ---------------------------------
@@ -430,9 +486,13 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
         // otherwise serve the larger of the two traversal queues.
         const bool run_shade = nS >= RTW_S_HI || (nT < RTW_T_LO && nL < RTW_T_LO && nS > 0u);
         const bool run_leaf = RTW_L_HI ? (nL >= RTW_L_HI || nT == 0u) : (nL > nT);
+#ifdef RTW_STAMP
+        const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+        const int which = run_shade ? 2 : (run_leaf ? 1 : 0);
+#endif
         if (!run_shade && !run_leaf) {
             c_steps[0]++; c_lanes[0] += nT;
-            if (ph == PH_TRAV) { n_nodes++; ph = trav_node(A.bvh, tr, stack); }
+            if (ph == PH_TRAV) { n_nodes++; ph = LDSN ? trav_node_lds(lnodes, tr, (short *)stack) : trav_node(A.bvh, tr, (int *)stack); }
         } else if (!run_shade) {
             c_steps[1]++; c_lanes[1] += nL;
             if (ph == PH_LEAF) {
@@ -462,7 +522,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                     if (newpath) { newpath = false; start_path(A, px, pt); n_rays++; }
                     // d. start the next closest-hit query
                     if (A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
-                        pt.L = mk(0, 0, 0);
+                        pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
                         if (finish_path(A, px, pt, n_nan)) have = false; else newpath = true;
                     } else {
                         ph = trav_begin<MOVING>(A, pt, tr, n_tests);
@@ -471,10 +531,18 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                 }
             }
         }
+#ifdef RTW_STAMP
+        // diagnostic build only: wave-cycles per phase (s_memtime), written to stats[11..13]
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        c_time[which] += __builtin_amdgcn_s_memtime() - t_begin;
+#endif
     }
     flush_counters(A, n_seg, n_rays, n_nan, n_tests, n_nodes);
     if ((threadIdx.x & 63u) == 0) {
         for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[5 + k], (unsigned long long)c_steps[k]); atomicAdd(&A.stats[8 + k], c_lanes[k]); }
+#ifdef RTW_STAMP
+        for (int k = 0; k < 3; k++) atomicAdd(&A.stats[11 + k], c_time[k]);
+#endif
     }
 }
 
@@ -482,18 +550,21 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
 // host side
 // ================================================================================================
 typedef void (*kernel_fn)(const KArgs);
-static kernel_fn pick_kernel(bool moving, uint32_t accel) {
-    if (accel == RTW_ACCEL_BVH) return moving ? render_bvh<true> : render_bvh<false>;
+static kernel_fn pick_kernel(bool moving, uint32_t accel, bool lds_nodes) {
+    if (accel == RTW_ACCEL_BVH) {
+        if (lds_nodes) return moving ? render_bvh<true, true> : render_bvh<false, true>;
+        return moving ? render_bvh<true, false> : render_bvh<false, false>;
+    }
     return moving ? render_brute<true> : render_brute<false>;
 }
 
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(pick_kernel(moving, accel), dim3(grid), dim3(RTW_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(pick_kernel(moving, accel, a.bvh.nodes16 != nullptr), dim3(grid), dim3(RTW_BLOCK), 0, stream, a);
 }
 
-uint32_t kernel_blocks_per_cu(bool moving, uint32_t accel) {
+uint32_t kernel_blocks_per_cu(bool moving, uint32_t accel, bool lds_nodes) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pick_kernel(moving, accel), RTW_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pick_kernel(moving, accel, lds_nodes), RTW_BLOCK, 0) != hipSuccess || n < 1) n = 1;
     return (uint32_t)(n > 8 ? 8 : n);
 }
 

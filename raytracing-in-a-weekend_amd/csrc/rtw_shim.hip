@@ -6,6 +6,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -31,7 +33,7 @@ struct rtw_ctx {
     float bg[3] = { 0, 0, 0 };
     void *d_geom = nullptr, *d_vel = nullptr, *d_mat = nullptr, *d_tex = nullptr, *d_texels = nullptr;
     DevBvh bvh{};
-    void *d_nodes = nullptr, *d_big_geom = nullptr, *d_big_vel = nullptr, *d_big_index = nullptr;
+    void *d_nodes = nullptr, *d_nodes16 = nullptr, *d_big_geom = nullptr, *d_big_vel = nullptr, *d_big_index = nullptr;
     // scratch
     uint32_t *d_queue = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -96,7 +98,7 @@ int rtw_ctx_create(int device, rtw_ctx **out) {
 }
 
 static void free_scene(rtw_ctx *c) {
-    void **bufs[] = { &c->d_geom, &c->d_vel, &c->d_mat, &c->d_tex, &c->d_texels, &c->d_nodes, &c->d_big_geom, &c->d_big_vel, &c->d_big_index };
+    void **bufs[] = { &c->d_geom, &c->d_vel, &c->d_mat, &c->d_tex, &c->d_texels, &c->d_nodes, &c->d_nodes16, &c->d_big_geom, &c->d_big_vel, &c->d_big_index };
     for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
     c->has_scene = false;
 }
@@ -161,6 +163,9 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     build_bvh(s->spheres, s->n_spheres, std::fmin(t_begin, t_end), std::fmax(t_begin, t_end), bb);
     std::vector<f4> big_geom, big_vel;
     for (uint32_t i : bb.big) { big_geom.push_back(geom[i]); big_vel.push_back(vel[i]); }
+    if ((rc = upload(&c->d_nodes16, bb.nodes16))) { free_scene(c); return rc; }
+    c->bvh.nodes16 = bb.nodes16.empty() ? nullptr : (const BvhNode16 *)c->d_nodes16;
+    c->bvh.n_nodes = (uint32_t)bb.nodes.size();
     if ((rc = upload(&c->d_nodes, bb.nodes)) || (rc = upload(&c->d_big_geom, big_geom)) ||
         (rc = upload(&c->d_big_vel, big_vel)) || (rc = upload(&c->d_big_index, bb.big))) { free_scene(c); return rc; }
     c->bvh.nodes = (const BvhNode *)c->d_nodes;
@@ -185,7 +190,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     if (!c || !cam || !p || !out_rgb) return RTW_E_INVALID;
     if (!c->has_scene) return RTW_E_NO_SCENE;
     if (p->width == 0 || p->height == 0 || p->samples == 0) return RTW_E_INVALID;
-    if (p->integrator > RTW_INTEGRATOR_FLAG || p->sampler > RTW_SAMPLER_NO_RAND || p->accel > RTW_ACCEL_BVH) return RTW_E_INVALID;
+    if (p->integrator > RTW_INTEGRATOR_RUST2 || p->sampler > RTW_SAMPLER_NO_RAND || p->accel > RTW_ACCEL_BVH) return RTW_E_INVALID;
     if (p->part_count > 1 && (p->row_block == 0 || p->part_index >= p->part_count)) return RTW_E_INVALID;
     if ((uint64_t)p->width * p->height >= (1ull << 32)) return RTW_E_INVALID;
     auto t0 = std::chrono::steady_clock::now();
@@ -194,6 +199,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     KArgs a;
     std::memset(&a, 0, sizeof a);
     a.cam = *cam; a.sc = c->sc; a.bvh = c->bvh;
+    if (p->flags & RTW_FLAG_GLOBAL_NODES) a.bvh.nodes16 = nullptr;
     a.width = p->width; a.height = p->height;
     a.n_rows = rtw_part_rows(p->height, p->row_block, p->part_index, p->part_count);
     a.row_block = p->row_block ? p->row_block : 1; a.part_index = p->part_index; a.part_count = p->part_count;
@@ -228,7 +234,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     }
 
     // persistent grid: as many workgroups as the kernel's registers let be resident, capped by the work
-    uint32_t per_cu = kernel_blocks_per_cu(c->sc.moving != 0, p->accel);
+    uint32_t per_cu = kernel_blocks_per_cu(c->sc.moving != 0, p->accel, c->bvh.nodes16 != nullptr && !(p->flags & RTW_FLAG_GLOBAL_NODES));
     uint32_t grid = (uint32_t)c->n_cu * per_cu;
     const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
     if (grid > need) grid = need ? need : 1;
@@ -252,6 +258,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
         stats->nan_pixels = (uint32_t)h_stats[4]; stats->rows = a.n_rows;
         stats->kernel_ms = ms;
         for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
+        if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu\n", h_stats[11], h_stats[12], h_stats[13]);
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return RTW_OK;

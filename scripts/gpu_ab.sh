@@ -2,7 +2,7 @@
 # A/B the default build against variant libraries on the default bench (GPU box).
 # usage: scripts/gpu_ab.sh [variant.so ...]   (names relative to raytracing-in-a-weekend_amd/)
 run() {
-  timeout -k 10 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | python3 -c "
+  timeout -k 10 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

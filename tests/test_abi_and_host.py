@@ -133,3 +133,65 @@ def test_python_viewport_mirrors_the_pod():
     assert cam.time0 == np.float32(3) / np.float32(60) and cam.shutter == 0.25
     p = vp.params(R.INTEGRATOR_BG_COLOR, R.SAMPLER_ROW, R.ACCEL_BRUTE)
     assert (p.integrator, p.sampler, p.accel, p.samples, p.depth) == (1, 0, 0, 10, 10)
+
+
+# ---- scene wire format + image writers -----------------------------------------
+def test_json_round_trip_like_deserialize_test():
+    """Rust/src/viewport/json_tests.rs:48-92: scene -> JsonValue -> Scene compares equal."""
+    import json
+    scene = R.Scene.new_sphere([R.Sphere.new((-0.5, 0.0, -1.0), 0.5, (0.6, 0.6, 0.6), R.SCATTER_M),
+                                R.Sphere.new((0.5, 0.0, -1.0), 0.5, (1.0, 1.0, 1.0), R.SCATTER_M),
+                                R.Sphere.new((0.0, 0.0, -2.0), 1.0, (0.5, 1.0, 0.0), R.METALLIC_M),
+                                R.Sphere.new_moving((2.4, 0.0, -0.8), 1.4, (0.9, 0.9, 0.9), R.GLASS_M, (0.0, 60.0, 0.0))])
+    text = scene.to_json()
+    doc = json.loads(text)                                         # it is valid JSON with the reference's members
+    assert set(doc["spheres"][0]) == {"origin", "radius", "col_mod", "material", "velocity", "texture"}
+    assert set(doc["spheres"][0]["material"]) == {"metallicness", "opacity", "ir"}
+    assert doc["spheres"][3]["velocity"] == {"x": 0, "y": 60, "z": 0}
+    assert doc["spheres"][0]["texture"] == {"row": 1, "col": 1, "img": [doc["spheres"][0]["col_mod"]]}
+    back = R.Scene.from_json(text)
+    assert back.n_spheres == 4
+    assert bytes(back._spheres)[: 80 * 4] == bytes(scene._spheres)[: 80 * 4]      # bit-exact f32 round trip
+
+
+def test_json_textured_scene_and_cpp_dialect_and_errors():
+    sc = R.Scene.generate(R.SCENE_C5)
+    back = R.Scene.from_json(sc.to_json())
+    assert back.n_spheres == sc.n_spheres and back.n_textures == 1 and back.n_texels == 8
+    assert bytes(back._spheres)[: 80 * sc.n_spheres] == bytes(sc._spheres)[: 80 * sc.n_spheres]
+    assert np.array_equal(back._texels[:8], sc._texels[:8])
+    # the C++ dialect has neither velocity nor texture (C++/headers/sphere.h:28-31)
+    cpp = '{"spheres":[{"origin":{"x":-0.52,"y":0,"z":-1.2},"radius":0.4,"material":{"metallicness":1,"opacity":0,"ir":1},"col_mod":{"x":0.7,"y":0.7,"z":0.7}}]}'
+    s = R.Scene.from_json(cpp)
+    assert s.n_spheres == 1 and s._spheres[0].tex == -1 and list(s._spheres[0].tex_color) == [1, 1, 1]
+    assert abs(s._spheres[0].center[0] + 0.52) < 1e-7
+    for bad in ('{"spheres":3}', '{"spheres":[{"origin":{"x":0,"y":0},"radius":1}]}', '{"spheres":[', 'nonsense', '{}'):
+        with pytest.raises(R.RtwError):
+            R.Scene.from_json(bad)
+
+
+def test_png_and_ppm_writers(tmp_path):
+    import struct, zlib
+    rng = np.random.default_rng(1)
+    img = rng.uniform(-0.1, 1.1, (7, 5, 3)).astype(np.float32)
+    png = str(tmp_path / "a.png")
+    R.write_img_f32(img, png)
+    raw = open(png, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(raw):
+        n, t = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(t + data) & 0xFFFFFFFF
+        chunks[t] = data
+        pos += 12 + n
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    assert (w, h, depth, ctype) == (5, 7, 8, 2)
+    pix = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), np.uint8).reshape(7, 1 + 5 * 3)
+    assert (pix[:, 0] == 0).all() and np.array_equal(pix[:, 1:].reshape(7, 5, 3), R.quantize_u8(img))
+    ppm = str(tmp_path / "a.ppm")
+    R.write_ppm(ppm, np.clip(img, 0, 1))
+    tok = open(ppm).read().split()
+    assert tok[:4] == ["P3", "5", "7", "255"]
+    want = (255 * np.clip(img, 0, 1).astype(np.float64)).astype(np.int32)       # RGB.cpp:16-20 truncation
+    assert np.array_equal(np.array(tok[4:], np.int32).reshape(7, 5, 3), want)

@@ -333,3 +333,52 @@ def test_oracle_vs_reference_objects_statistical():
     assert np.abs(da).max() < 0.06, np.abs(da).max()
     # mean path length agrees (the C++ loop counts one query per ray_colorD call that reaches the loop)
     assert abs(sa.segments / sa.camera_rays - seg / sa.camera_rays) < 0.02
+
+
+# ---- 9. Rust2 trait surface ----------------------------------------------------------
+def rust2_view(w=64, h=36, samples=9, depth=6):
+    spheres = [R.Sphere.with_albedo((0, -100.5, -1), 100.0, (0.5, 0.5, 0.5), R.SCATTER_M),       # Lambertian
+               R.Sphere.with_albedo((0, 0, -1.2), 0.5, (0.7, 0.3, 0.3), R.SCATTER_M),
+               R.Sphere.with_albedo((1.05, 0, -1.2), 0.5, (0.8, 0.6, 0.2), R.METALLIC_M),        # Mirror
+               R.Sphere.with_albedo((-1.05, 0, -1.2), 0.5, (1, 1, 1), R.GLASS_M)]                # MirrorGlass{1.5}
+    spheres[1].pod.emitted[0] = 0.25                                                              # ColorResult.emmited
+    scene = R.Scene(spheres, background=(0.6, 0.7, 0.9))
+    cam = R.camera2_new(np.float32(w) / np.float32(h), (0, 0, 0.5), (0, 1, 0), (0, 0, -1), 80.0, 0.01)
+    p = flag_params(depth=depth)
+    p.width, p.height, p.samples, p.integrator, p.sampler, p.gamma, p.maxt = w, h, samples, R.INTEGRATOR_RUST2, R.SAMPLER_CENTRES, 2.0, 1000.0
+    return scene, cam, p
+
+
+def test_rust2_camera_and_sampler():
+    cam = R.camera2_new(2.0, (1, 2, 3), (0, 1, 0), (0, 0, -1), 90.0, 0.1)
+    np.testing.assert_allclose(np.array(cam.pixel00), [-2, 1, -1], atol=1e-6)          # left_top = -w - vu/2 - vv/2
+    np.testing.assert_allclose(np.array(cam.delta_u), [4, 0, 0], atol=1e-6)            # FULL viewport vectors
+    np.testing.assert_allclose(np.array(cam.delta_v), [0, -2, 0], atol=1e-6)
+    scene, cam, p = rust2_view(samples=500)
+    _, st = O.render(cam, scene, p, threads=4)
+    assert st.camera_rays == 64 * 36 * 484                                             # floor(sqrt(500))^2
+    assert np.array_equal(R.quantize_u8_rust2(np.float32([0.0, 0.5, 1.0, 2.0])), np.uint8([0, 128, 255, 255]))
+
+
+def test_rust2_ray_color_semantics():
+    scene, cam, p = rust2_view()
+    # depth 0 returns the background, not black (Rust2/src/viewport/ray_color.rs:13-16)
+    p.depth, p.gamma = 0, 1.0
+    img, st = O.render(cam, scene, p, threads=2)
+    assert st.segments == 0
+    np.testing.assert_allclose(img, np.broadcast_to(np.float32([0.6, 0.7, 0.9]), img.shape), rtol=1e-6)
+    # Mirror reflects the UN-normalised direction: |next| == |dir|
+    pp = flag_params(depth=1)
+    pp.integrator = R.INTEGRATOR_RUST2
+    b, _ = O.trace_ray((0, 0, 0.5), (3.0, 0.0, -4.8), 0.0, scene, pp)
+    # Lambertian direction is normalised
+    lam, _ = O.trace_ray((0, 0, 0.5), (0.0, 0.0, -1.0), 0.0, scene, pp)
+    assert lam[0].hit == 1 and lam[0].sphere == 1
+    # recursion order vs front-to-back: same paths, colours within a few ulp
+    scene, cam, p = rust2_view(samples=16)
+    a, sa = O.render(cam, scene, p)
+    p.flags = R.FLAG_RECURSIVE_ORDER
+    c, sc = O.render(cam, scene, p)
+    assert sa.segments == sc.segments
+    np.testing.assert_allclose(a, c, rtol=3e-6, atol=1e-7)
+    assert a[..., 0].max() > a[..., 2].min()      # the emissive red sphere shows
