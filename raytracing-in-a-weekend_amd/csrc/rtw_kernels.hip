@@ -307,6 +307,12 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 #ifndef RTW_S_HI
 #define RTW_S_HI 48u            /* lanes waiting in SHADE that trigger a SHADE step */
 #endif
+#ifndef RTW_TRAV_UNROLL
+#define RTW_TRAV_UNROLL 3       /* max node visits per scheduling decision */
+#endif
+#ifndef RTW_T_KEEP
+#define RTW_T_KEEP 1u           /* a burst ends early when fewer lanes than this are still traversing */
+#endif
 #ifndef RTW_L_HI
 #define RTW_L_HI 0u             /* lanes waiting in LEAF that pre-empt TRAVERSE (0: the larger queue runs) */
 #endif
@@ -492,7 +498,16 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
 #endif
         if (!run_shade && !run_leaf) {
             c_steps[0]++; c_lanes[0] += nT;
-            if (ph == PH_TRAV) { n_nodes++; ph = LDSN ? trav_node_lds(lnodes, tr, (short *)stack) : trav_node(A.bvh, tr, (int *)stack); }
+            // Up to RTW_TRAV_UNROLL node visits per scheduling decision, while at least RTW_T_KEEP lanes are
+            // still traversing: the scheduler's ballots and branches are paid once per burst, and lanes
+            // that left TRAVERSE (leaf reached / query done) sit out only the rest of the burst.
+            for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
+                if (ph == PH_TRAV) { n_nodes++; ph = LDSN ? trav_node_lds(lnodes, tr, (short *)stack) : trav_node(A.bvh, tr, (int *)stack); }
+                if (u + 1 >= RTW_TRAV_UNROLL) break;
+                const uint32_t live = (uint32_t)__popcll(__ballot(ph == PH_TRAV));
+                if (live < RTW_T_KEEP) break;
+                c_steps[0]++; c_lanes[0] += live;                // census of the extra visit
+            }
         } else if (!run_shade) {
             c_steps[1]++; c_lanes[1] += nL;
             if (ph == PH_LEAF) {

@@ -235,6 +235,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
 
     // persistent grid: as many workgroups as the kernel's registers let be resident, capped by the work
     uint32_t per_cu = kernel_blocks_per_cu(c->sc.moving != 0, p->accel, c->bvh.nodes16 != nullptr && !(p->flags & RTW_FLAG_GLOBAL_NODES));
+    if (const char *e = getenv("RTW_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = (uint32_t)v; }   // occupancy experiments
     uint32_t grid = (uint32_t)c->n_cu * per_cu;
     const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
     if (grid > need) grid = need ? need : 1;
