@@ -49,7 +49,21 @@ def cpu_baseline(R, scene, cam, p):
     q.samples = int(max(2, min(p.samples, round(2 * target_s * rate / max(st.segments, 1)))))
     _, st = O.render(cam, scene, q, threads)
     sec = st.total_ms / 1e3
-    return {"value": round(st.segments / sec / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+    extra = {}
+    if O.have_ref():
+        # the reference's own C++ objects (oracle/_ref: Sphere::collisionNormal -> Material::onHit), serial like
+        # C++/src/viewport.cpp, 1 core, on a much smaller slice (it is ~30x slower than the 16-thread port)
+        r = R.RtwParams.from_buffer_copy(p)
+        r.width, r.height, r.samples, r.part_count = p.width // 8, p.height // 8, 4, 1
+        cam_s = R.RtwCamera.from_buffer_copy(cam)
+        for k in range(3):
+            cam_s.pixel00[k] = cam.pixel00[k] - 0.5 * (cam.delta_u[k] + cam.delta_v[k]) + 4.0 * (cam.delta_u[k] + cam.delta_v[k])
+            cam_s.delta_u[k] = cam.delta_u[k] * 8
+            cam_s.delta_v[k] = cam.delta_v[k] * 8
+        _, seg_ref, sec_ref = O.ref_render(cam_s, scene, r, rand_seed=1)
+        extra = {"reference_cpp_objects_1core": {"value": round(seg_ref / sec_ref / 1e6, 4), "unit": "Msamples/s", "cores": 1,
+                                                 "sample": f"{r.width}x{r.height}x{r.samples} spp of the same view, {seg_ref} segments in {sec_ref:.2f} s"}}
+    return {**extra, "value": round(st.segments / sec / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": f"oracle/rtw_oracle.c (f32 restatement of the Rust path, one task per row), rows of every 17th 8-row block "
                       f"({st.rows} rows) x {q.width} px x {q.samples} spp of the same frame, {st.segments} segments in {sec:.2f} s",
             "camera_msamples_per_s": round(st.camera_rays / sec / 1e6, 4)}
@@ -117,14 +131,14 @@ def main():
     fence()
     t0 = time.perf_counter()
     seg = rays = nodes = tests = 0
-    steps3, lanes3 = [0, 0, 0], [0, 0, 0]
+    steps3, lanes3 = [0, 0, 0, 0], [0, 0, 0, 0]
     kernel_ms = 0.0
     frame = None
     for _ in range(args.steps):
         frame, st = step()
         seg += st.segments; rays += st.camera_rays; nodes += st.node_tests; tests += st.sphere_tests
         kernel_ms += st.kernel_ms
-        for k in range(3):
+        for k in range(4):
             steps3[k] += st.phase_steps[k]; lanes3[k] += st.phase_lanes[k]
     fence()
     elapsed = time.perf_counter() - t0
@@ -159,7 +173,7 @@ def main():
                          "algorithmic_flop_per_launch": flop,
                          "scheduler_census_rank0": {n: {"wave_steps": steps3[k] // args.steps,
                                                             "simd_efficiency": round(lanes3[k] / max(1, 64 * steps3[k]), 4)}
-                                                        for k, n in enumerate(("traverse", "leaf", "shade"))},
+                                                        for k, n in enumerate(("traverse", "leaf", "shade", "hit"))},
                          "units_per_launch": {"segments": seg / args.steps / world, "node_visits": nodes / args.steps / world,
                                               "sphere_tests": tests / args.steps / world},
                          "hbm": {"achieved": round(H * W * 12 / world / k_s / 1e9, 4), "peak": 8000.0, "unit": "GB/s",

@@ -113,19 +113,20 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
     pt.o = o; pt.d = d; pt.tm = tm;
 }
 
-// One step of ray_color_* after a closest-hit query returned (best, best_t).  Returns true when the
-// path is finished (pt.L is then its radiance).
+// ray_color_* when the closest-hit query found nothing: sky / background ends the path.
+__device__ __forceinline__ void shade_miss(const KArgs &A, Path &pt) {
+    v3 miss;
+    if (A.integrator == RTW_INTEGRATOR_BG_COLOR || A.integrator == RTW_INTEGRATOR_RUST2) miss = ld3(A.bg);
+    else if (A.integrator == RTW_INTEGRATOR_FLAG) miss = mk(0.0f, 0.0f, 1.0f);
+    else miss = sky_gradient(pt.d);
+    pt.L = pt.L + miss * pt.thr;
+}
+
+// One step of ray_color_* at the closest hit (best >= 0, best_t).  Returns true when the path is finished
+// (pt.L is then its radiance).
 template <bool MOVING>
-__device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float best_t) {
+__device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, float best_t) {
     const DevScene &sc = A.sc;
-    if (best < 0) {
-        v3 miss;
-        if (A.integrator == RTW_INTEGRATOR_BG_COLOR || A.integrator == RTW_INTEGRATOR_RUST2) miss = ld3(A.bg);
-        else if (A.integrator == RTW_INTEGRATOR_FLAG) miss = mk(0.0f, 0.0f, 1.0f);
-        else miss = sky_gradient(pt.d);
-        pt.L = pt.L + miss * pt.thr;
-        return true;
-    }
     f4 g = sc.geom[best];
     v3 c = mk(g.x, g.y, g.z);
     if (MOVING) { f4 vv = sc.vel[best]; c = c + mk(vv.x, vv.y, vv.z) * pt.tm; }
@@ -166,6 +167,12 @@ __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float 
         return true;
     }
     return false;
+}
+
+template <bool MOVING>
+__device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float best_t) {
+    if (best < 0) { shade_miss(A, pt); return true; }
+    return shade_hit<MOVING>(A, pt, best, best_t);
 }
 
 // A path ended: add it to the pixel; when the pixel is complete, resolve and store it.
@@ -215,13 +222,9 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
     const float a = dot(d, d);
     best = -1; best_t = 0.0f;
     const uint32_t n = sc.n;
-    for (uint32_t s = 0; s < n; ++s) {
-        f4 g = geom[s];
+    auto test = [&](f4 g, f4 vv, uint32_t s) {
         float cx = g.x, cy = g.y, cz = g.z;
-        if (MOVING) {                      // sphere.rs:100  origin + velocity * r.time
-            f4 vv = vel[s];
-            cx = cx + vv.x * tm; cy = cy + vv.y * tm; cz = cz + vv.z * tm;
-        }
+        if (MOVING) { cx = cx + vv.x * tm; cy = cy + vv.y * tm; cz = cz + vv.z * tm; }   // sphere.rs:100  origin + velocity * r.time
         float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
         float b = ocx * d.x + ocy * d.y + ocz * d.z;
         float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
@@ -234,7 +237,25 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
                 if (best < 0 || best_t > x) { best = (int)s; best_t = x; }
             }
         }
+    };
+    const f4 zero = { 0, 0, 0, 0 };
+    uint32_t s = 0;
+    // four spheres per trip, software-pipelined: the scalar loads (one s_load_dwordx16) of the NEXT four are
+    // issued before the current four are tested, so their latency hides behind ~70 VALU ops; list order is kept
+    f4 n0 = zero, n1 = zero, n2 = zero, n3 = zero, w0 = zero, w1 = zero, w2 = zero, w3 = zero;
+    if (n >= 4) {
+        n0 = geom[0]; n1 = geom[1]; n2 = geom[2]; n3 = geom[3];
+        if (MOVING) { w0 = vel[0]; w1 = vel[1]; w2 = vel[2]; w3 = vel[3]; }
     }
+    for (; s + 4 <= n; s += 4) {
+        const f4 g0 = n0, g1 = n1, g2 = n2, g3 = n3, v0 = w0, v1 = w1, v2 = w2, v3 = w3;
+        if (s + 8 <= n) {
+            n0 = geom[s + 4]; n1 = geom[s + 5]; n2 = geom[s + 6]; n3 = geom[s + 7];
+            if (MOVING) { w0 = vel[s + 4]; w1 = vel[s + 5]; w2 = vel[s + 6]; w3 = vel[s + 7]; }
+        }
+        test(g0, v0, s); test(g1, v1, s + 1); test(g2, v2, s + 2); test(g3, v3, s + 3);
+    }
+    for (; s < n; ++s) test(geom[s], MOVING ? vel[s] : zero, s);
 }
 
 template <bool MOVING>
@@ -307,6 +328,14 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 #ifndef RTW_S_HI
 #define RTW_S_HI 48u            /* lanes waiting in SHADE that trigger a SHADE step */
 #endif
+#ifndef RTW_SPLIT_SHADE
+#define RTW_SPLIT_SHADE 0       /* 1: hits are scattered in their own phase (HIT), apart from path start/end (SHADE).
+                                   Measured on the bench frame: 10.8 vs 14.9 Gsegments/s -- the extra queueing costs more
+                                   than the denser steps save, so it stays off (kept for experiments). */
+#endif
+#ifndef RTW_H_HI
+#define RTW_H_HI 40u            /* lanes waiting in HIT that trigger a HIT step */
+#endif
 #ifndef RTW_TRAV_UNROLL
 #define RTW_TRAV_UNROLL 3       /* max node visits per scheduling decision */
 #endif
@@ -331,7 +360,7 @@ struct Trav {                // traversal state of one lane
     float tau_t, lo_lim, hi_lim;
 };
 
-enum { PH_SHADE = 0, PH_TRAV = 1, PH_LEAF = 2, PH_DEAD = 3 };
+enum { PH_SHADE = 0, PH_TRAV = 1, PH_LEAF = 2, PH_DEAD = 3, PH_HIT = 4 };
 
 // Begin a closest-hit query: big spheres, per-ray constants, root.  Returns the phase to enter.
 template <bool MOVING>
@@ -474,29 +503,71 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
     Trav tr; tr.node = 0; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
     uint32_t n_seg = 0, n_rays = 0, n_nan = 0, n_nodes = 0, n_tests = 0;
-    uint32_t c_steps[3] = { 0, 0, 0 };              // wave-uniform (SGPR) census of the scheduler
-    unsigned long long c_lanes[3] = { 0, 0, 0 };
+    bool path_done = false;                         // a finished path waits for PH_SHADE to bank it
+    uint32_t c_steps[4] = { 0, 0, 0, 0 };           // wave-uniform (SGPR) census of the scheduler
+    unsigned long long c_lanes[4] = { 0, 0, 0, 0 };
 #ifdef RTW_STAMP
-    unsigned long long c_time[3] = { 0, 0, 0 };
+    unsigned long long c_time[4] = { 0, 0, 0, 0 };
 #endif
 
     for (;;) {
-        // ---- scheduler: run the phase most lanes are waiting for ---------------------------------
+        // ---- scheduler ---------------------------------------------------------------------------
+        // Phases: TRAVERSE (inner-node visits), LEAF (one exact sphere test), HIT (scatter at the closest
+        // hit: Material::on_hit, then set up the next query) and SHADE (everything that ends or starts a
+        // path: sky/background for a miss, add the path to the pixel, resolve + next pixel, camera ray,
+        // set up the query).  HIT and SHADE are the expensive steps (several hundred instructions): each
+        // runs when enough lanes have piled up in it (RTW_H_HI / RTW_S_HI) or when little traversal work
+        // is left to hide behind (RTW_T_LO); otherwise the larger of the two traversal queues runs.
         const uint32_t nT = (uint32_t)__popcll(__ballot(ph == PH_TRAV));
         const uint32_t nL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
         const uint32_t nS = (uint32_t)__popcll(__ballot(ph == PH_SHADE));
-        if ((nT | nL | nS) == 0u) break;                     // every lane is PH_DEAD
-
-        // SHADE is the expensive step (several hundred instructions): run it when enough lanes have
-        // piled up in it (RTW_S_HI) or when little traversal work is left to hide behind (RTW_T_LO);
-        // otherwise serve the larger of the two traversal queues.
-        const bool run_shade = nS >= RTW_S_HI || (nT < RTW_T_LO && nL < RTW_T_LO && nS > 0u);
+        const uint32_t nH = (uint32_t)__popcll(__ballot(ph == PH_HIT));
+        if ((nT | nL | nS | nH) == 0u) break;                // every lane is PH_DEAD
+        bool run_hit = nH >= RTW_H_HI, run_shade = nS >= RTW_S_HI;
+        if (!run_hit && !run_shade && nT < RTW_T_LO && nL < RTW_T_LO) { run_hit = nH >= nS && nH > 0u; run_shade = !run_hit && nS > 0u; }
+        if (run_hit && run_shade) { if (nH >= nS) run_shade = false; else run_hit = false; }
         const bool run_leaf = RTW_L_HI ? (nL >= RTW_L_HI || nT == 0u) : (nL > nT);
 #ifdef RTW_STAMP
         const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-        const int which = run_shade ? 2 : (run_leaf ? 1 : 0);
+        const int which = run_hit ? 3 : (run_shade ? 2 : (run_leaf ? 1 : 0));
 #endif
-        if (!run_shade && !run_leaf) {
+        bool want_query = false;                             // lanes that start a closest-hit query this trip
+        if (run_hit) {
+            c_steps[3]++; c_lanes[3] += nH;
+            if (ph == PH_HIT) {
+                n_seg++;
+                if (shade_hit<MOVING>(A, pt, tr.best, tr.best_t)) { path_done = true; inflight = false; ph = PH_SHADE; }
+                else want_query = true;
+            }
+        } else if (run_shade) {
+            c_steps[2]++; c_lanes[2] += nS;
+            if (ph == PH_SHADE) {
+                // a. the closest-hit query this lane was waiting on missed everything
+                if (inflight) {
+                    inflight = false;
+                    n_seg++;
+#if RTW_SPLIT_SHADE
+                    shade_miss(A, pt); path_done = true;                   // hits went to PH_HIT
+#else
+                    path_done = shade<MOVING>(A, pt, tr.best, tr.best_t);
+#endif
+                }
+                if (path_done) { path_done = false; if (finish_path(A, px, pt, n_nan)) have = false; else newpath = true; }
+                // b. next pixel (one atomic per wave for all lanes that need one)
+                bool exhausted = false;
+                if (fetch_pixel(A, !have, px, exhausted)) { have = true; newpath = true; }
+                if (exhausted) ph = PH_DEAD;
+                if (have) {
+                    // c. next camera ray.  A lane whose path continues (split off: hit shaded here) keeps its ray.
+                    if (newpath) { newpath = false; start_path(A, px, pt); n_rays++; }
+                    // d. start the next closest-hit query
+                    if (A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
+                        pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
+                        path_done = true;                                  // banked on the next SHADE trip
+                    } else want_query = true;
+                }
+            }
+        } else if (!run_leaf) {
             c_steps[0]++; c_lanes[0] += nT;
             // Up to RTW_TRAV_UNROLL node visits per scheduling decision, while at least RTW_T_KEEP lanes are
             // still traversing: the scheduler's ballots and branches are paid once per burst, and lanes
@@ -508,7 +579,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                 if (live < RTW_T_KEEP) break;
                 c_steps[0]++; c_lanes[0] += live;                // census of the extra visit
             }
-        } else if (!run_shade) {
+        } else {
             c_steps[1]++; c_lanes[1] += nL;
             if (ph == PH_LEAF) {
                 const uint32_t s = (uint32_t)~tr.node;
@@ -517,37 +588,15 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                 tr.hi_lim = tr.best_t + tr.tau_t;
                 ph = trav_pop(tr, stack);
             }
-        } else {
-            c_steps[2]++; c_lanes[2] += nS;
-            if (ph == PH_SHADE) {
-                // a. the closest-hit query this lane was waiting on is complete
-                if (inflight) {
-                    inflight = false;
-                    n_seg++;
-                    if (shade<MOVING>(A, pt, tr.best, tr.best_t)) {
-                        if (finish_path(A, px, pt, n_nan)) have = false; else newpath = true;
-                    }
-                }
-                // b. next pixel (one atomic per wave for all lanes that need one)
-                bool exhausted = false;
-                if (fetch_pixel(A, !have, px, exhausted)) { have = true; newpath = true; }
-                if (exhausted) ph = PH_DEAD;
-                if (have) {
-                    // c. next camera ray
-                    if (newpath) { newpath = false; start_path(A, px, pt); n_rays++; }
-                    // d. start the next closest-hit query
-                    if (A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
-                        pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
-                        if (finish_path(A, px, pt, n_nan)) have = false; else newpath = true;
-                    } else {
-                        ph = trav_begin<MOVING>(A, pt, tr, n_tests);
-                        inflight = true;
-                    }
-                }
-            }
         }
+        // one copy of the query set-up (big spheres + per-ray constants) for both expensive phases
+        if (run_hit || run_shade) {
+            if (want_query) { ph = trav_begin<MOVING>(A, pt, tr, n_tests); inflight = true; }
+        }
+        // a query that just completed with a hit goes to HIT, a miss (or a banked path) waits in SHADE
+        if (RTW_SPLIT_SHADE && ph == PH_SHADE && inflight && tr.best >= 0) ph = PH_HIT;
 #ifdef RTW_STAMP
-        // diagnostic build only: wave-cycles per phase (s_memtime), written to stats[11..13]
+        // diagnostic build only: wave-ticks per phase (s_memtime), written to stats[11..13]
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         c_time[which] += __builtin_amdgcn_s_memtime() - t_begin;
 #endif
@@ -555,8 +604,9 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
     flush_counters(A, n_seg, n_rays, n_nan, n_tests, n_nodes);
     if ((threadIdx.x & 63u) == 0) {
         for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[5 + k], (unsigned long long)c_steps[k]); atomicAdd(&A.stats[8 + k], c_lanes[k]); }
+        atomicAdd(&A.stats[14], (unsigned long long)c_steps[3]); atomicAdd(&A.stats[15], c_lanes[3]);
 #ifdef RTW_STAMP
-        for (int k = 0; k < 3; k++) atomicAdd(&A.stats[11 + k], c_time[k]);
+        for (int k = 0; k < 3; k++) atomicAdd(&A.stats[11 + k], c_time[k] + (k == 2 ? c_time[3] : 0ull));
 #endif
     }
 }
