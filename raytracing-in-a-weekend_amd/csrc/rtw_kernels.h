@@ -29,17 +29,20 @@ struct KArgs {
     DevScene  sc;
     DevBvh    bvh;
     uint32_t width, height;       // full image
-    uint32_t n_rows;              // rows of this partition (compact)
+    uint32_t k_base, k_end;       // compact rows [k_base, k_end) of this partition rendered by this launch (a band)
+    uint32_t n_tiles;             // tiles_x * ceil((k_end - k_base) / 8)
+    uint32_t chunk_len, n_chunks; // samples per work unit, units per pixel
+    float *samples;               // per-sample radiance, [n_tiles * n_chunks][64][chunk_len][3]
     uint32_t row_block, part_index, part_count;
     uint32_t tiles_x;             // ceil(width / 8)
-    uint32_t total_work;          // 64 * tiles_x * ceil(n_rows / 8)
+    uint32_t total_work;          // 64 * n_tiles * n_chunks
     uint32_t n_samples;           // rays per pixel actually traced (sampler-dependent)
     uint32_t s_root;              // strata per axis (STRATIFIED / CENTRES)
     uint32_t sampler, integrator, depth;
     uint32_t seed_lo, seed_hi;
     float inv_gamma, mint, maxt;
     float bg[3];
-    float *out;                   // [n_rows][width][3]
+    float *out;                   // [rows of the partition][width][3]
     uint32_t *queue;              // work-item counter, zeroed before launch
     unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels [5..7] phase steps [8..10] phase lanes
 };

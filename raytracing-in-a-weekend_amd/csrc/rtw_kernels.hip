@@ -31,11 +31,11 @@ namespace rtw {
 // shared pieces
 // ================================================================================================
 
-struct Pixel {            // the pixel a lane owns
-    uint32_t i, j, k;     // column, image row, compact row of this partition
+struct Pixel {            // the work unit a lane owns: a run of consecutive samples of one pixel
+    uint32_t i, j;        // column, image row
     uint32_t rng_base;    // hash of (seed, pixel)
-    uint32_t s;           // next sample index
-    v3 acc;               // sum of finished samples, in sample order
+    uint32_t s, s_end;    // next sample index, one past the last of this unit
+    uint32_t slot;        // where sample s goes in KArgs.samples (advances with s)
 };
 
 struct Path {             // the path a lane is tracing
@@ -48,32 +48,49 @@ struct Path {             // the path a lane is tracing
     bool poison;          // bg_color's 0/0 (ray_color.rs:72-75)
 };
 
+// Wave-local reserve of work items: the wave takes 64 consecutive items (one tile x chunk) from the global
+// queue with ONE atomic and hands them to its lanes as they run dry, so the queue word sees one atomic per
+// 64 units instead of one per refill (a single word saturates near 88 dequeues/us, MI355X_MICROARCH.md).
+struct Reserve { uint32_t next, end; };      // wave-uniform
+
 // Pull the next work item for the lanes with `need` set.  Must be called by all lanes of the wave
-// that are currently active; returns true for lanes that got a valid pixel.  `exhausted` is set for
-// lanes that found the queue empty.
-__device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px, bool &exhausted) {
+// that are currently active; returns true for lanes that got a valid unit.  `exhausted` is set for
+// lanes that found the queue empty.  Lanes that get nothing (reserve ran out mid-way, padding pixel)
+// simply ask again on the next trip.
+__device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px, bool &exhausted, Reserve &rs) {
     const unsigned long long m = __ballot(need);
     if (m == 0ull) return false;
-    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(A.queue, (uint32_t)__popcll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-    if (!need) return false;
+    if (rs.next == rs.end) {                                      // wave-uniform: refill the reserve
+        const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+        uint32_t base = 0;
+        if ((threadIdx.x & 63u) == leader) base = atomicAdd(A.queue, 64u);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+        rs.next = base < A.total_work ? base : A.total_work;      // total_work is a multiple of 64
+        rs.end = rs.next + (base < A.total_work ? 64u : 0u);
+    }
+    const uint32_t avail = rs.end - rs.next;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    const uint32_t w = base + rank;
-    if (w >= A.total_work) { exhausted = true; return false; }
-    // 8x8-tile-major order over the compact rows of this partition
-    const uint32_t tile = w >> 6, p = w & 63u;
+    const uint32_t w = rs.next + rank;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    rs.next += cnt < avail ? cnt : avail;
+    if (!need) return false;
+    if (avail == 0u) { exhausted = true; return false; }          // the queue is empty
+    if (rank >= avail) return false;                              // reserve ran out: next trip refills
+    // Work unit = (8x8 tile, chunk of RTW_CHUNK samples, pixel of the tile); units of one tile are consecutive,
+    // so the 64 lanes that pull together get the same chunk of the 64 pixels of one tile.
+    const uint32_t u = w >> 6, p = w & 63u;
+    const uint32_t tile = u / A.n_chunks, chunk = u - tile * A.n_chunks;
     const uint32_t tcol = tile % A.tiles_x, trow = tile / A.tiles_x;
     px.i = tcol * 8u + (p & 7u);
-    px.k = trow * 8u + (p >> 3);
-    if (!(px.i < A.width && px.k < A.n_rows)) return false;      // padding item: ask again next trip
-    px.j = px.k;   // compact row -> image row (RtwParams row partition)
-    if (A.part_count > 1) px.j = ((px.k / A.row_block) * A.part_count + A.part_index) * A.row_block + (px.k % A.row_block);
+    const uint32_t k = A.k_base + trow * 8u + (p >> 3);            // compact row of this partition
+    if (!(px.i < A.width && k < A.k_end)) return false;            // padding item: ask again next trip
+    px.j = k;   // compact row -> image row (RtwParams row partition)
+    if (A.part_count > 1) px.j = ((k / A.row_block) * A.part_count + A.part_index) * A.row_block + (k % A.row_block);
     px.rng_base = rng_pixel_base(A.seed_lo, A.seed_hi, px.j * A.width + px.i);
-    px.s = 0; px.acc = mk(0, 0, 0);
-    return true;
+    px.s = chunk * A.chunk_len;
+    px.s_end = px.s + A.chunk_len < A.n_samples ? px.s + A.chunk_len : A.n_samples;
+    px.slot = w * A.chunk_len;                                     // [unit][pixel of tile][sample of chunk]
+    return px.s < px.s_end;
 }
 
 // Camera ray of sample px.s (the sampler loops of viewport.rs / Rust2 viewport.rs).
@@ -175,30 +192,52 @@ __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float 
     return shade_hit<MOVING>(A, pt, best, best_t);
 }
 
-// A path ended: add it to the pixel; when the pixel is complete, resolve and store it.
-// Returns true when the pixel is done.
-__device__ __forceinline__ bool finish_path(const KArgs &A, Pixel &px, Path &pt, uint32_t &n_nan) {
+// A path ended: bank its radiance in the sample buffer (the resolve kernel adds the samples of a pixel
+// in sample order, viewport.rs:299).  Returns true when the unit is done.
+__device__ __forceinline__ bool finish_path(const KArgs &A, Pixel &px, Path &pt) {
     if (pt.poison) { const float qn = __builtin_nanf(""); pt.L = mk(qn, qn, qn); }
-    px.acc = px.acc + pt.L;                                  // viewport.rs:299
-    px.s++;
-    if (px.s < A.n_samples) return false;
-    v3 col = px.acc / (float)A.n_samples;                    // viewport.rs:301
-    // gamma_correct (viewport.rs:207-213).  x^1 is x: skipping the libm call keeps the gamma == 1
-    // output bit-identical to the CPU (ocml powf is not exact there).
-    if (A.inv_gamma != 1.0f) col = mk(powf(col.x, A.inv_gamma), powf(col.y, A.inv_gamma), powf(col.z, A.inv_gamma));
-    // one 12-byte store (float3 is a 4-byte-aligned struct of three floats)
-    *reinterpret_cast<float3 *>(A.out + 3 * ((size_t)px.k * A.width + px.i)) = make_float3(col.x, col.y, col.z);
-    if (col.x != col.x || col.y != col.y || col.z != col.z) n_nan++;
-    return true;
+    *reinterpret_cast<float3 *>(A.samples + 3 * (size_t)px.slot) = make_float3(pt.L.x, pt.L.y, pt.L.z);   // one 12-byte store
+    px.slot++; px.s++;
+    return px.s >= px.s_end;
 }
 
-__device__ __forceinline__ void flush_counters(const KArgs &A, uint32_t n_seg, uint32_t n_rays, uint32_t n_nan,
+// The pixel stage of the driver (viewport.rs:299-301): color = sum of the samples IN ORDER, / samples,
+// powf(1/gamma), one coalesced-by-tile 12-byte store per pixel.  One lane per pixel; the per-sample radiances
+// were banked by the render kernel as [unit = tile*n_chunks + chunk][pixel of tile][sample of chunk].
+__global__ __launch_bounds__(RTW_BLOCK) void resolve_kernel(const KArgs A) {
+    const uint32_t w = blockIdx.x * RTW_BLOCK + threadIdx.x;
+    const uint32_t tile = w >> 6, p = w & 63u;
+    uint32_t nan = 0;
+    if (tile < A.n_tiles) {
+        const uint32_t tcol = tile % A.tiles_x, trow = tile / A.tiles_x;
+        const uint32_t i = tcol * 8u + (p & 7u), k = A.k_base + trow * 8u + (p >> 3);
+        if (i < A.width && k < A.k_end) {
+            v3 acc = mk(0, 0, 0);
+            uint32_t s = 0;
+            for (uint32_t c = 0; c < A.n_chunks; c++) {
+                const float *src = A.samples + 3 * (size_t)(((tile * A.n_chunks + c) * 64u + p) * A.chunk_len);
+                const uint32_t cnt = s + A.chunk_len < A.n_samples ? A.chunk_len : A.n_samples - s;
+                for (uint32_t q = 0; q < cnt; q++) acc = acc + ld3(src + 3 * q);           // viewport.rs:299
+                s += cnt;
+            }
+            v3 col = acc / (float)A.n_samples;                   // viewport.rs:301
+            // gamma_correct (viewport.rs:207-213).  x^1 is x: skipping the libm call keeps the gamma == 1
+            // output bit-identical to the CPU (ocml powf is not exact there).
+            if (A.inv_gamma != 1.0f) col = mk(powf(col.x, A.inv_gamma), powf(col.y, A.inv_gamma), powf(col.z, A.inv_gamma));
+            *reinterpret_cast<float3 *>(A.out + 3 * ((size_t)k * A.width + i)) = make_float3(col.x, col.y, col.z);
+            if (col.x != col.x || col.y != col.y || col.z != col.z) nan = 1;
+        }
+    }
+    const unsigned long long m = __ballot(nan != 0);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&A.stats[4], (unsigned long long)__popcll(m));
+}
+
+__device__ __forceinline__ void flush_counters(const KArgs &A, uint32_t n_seg, uint32_t n_rays,
                                                unsigned long long tests, uint32_t n_nodes) {
-    unsigned long long seg = n_seg, rays = n_rays, nans = n_nan, nodes = n_nodes;
+    unsigned long long seg = n_seg, rays = n_rays, nodes = n_nodes;
     for (int off = 32; off > 0; off >>= 1) {
         seg += __shfl_down(seg, off);
         rays += __shfl_down(rays, off);
-        nans += __shfl_down(nans, off);
         nodes += __shfl_down(nodes, off);
         tests += __shfl_down(tests, off);
     }
@@ -207,7 +246,6 @@ __device__ __forceinline__ void flush_counters(const KArgs &A, uint32_t n_seg, u
         atomicAdd(&A.stats[1], seg);
         atomicAdd(&A.stats[2], tests);
         atomicAdd(&A.stats[3], nodes);
-        atomicAdd(&A.stats[4], nans);
     }
 }
 
@@ -261,12 +299,13 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
 template <bool MOVING>
 __global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
-    Pixel px; px.i = px.j = px.k = px.rng_base = px.s = 0; px.acc = mk(0, 0, 0);
+    Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
+    Reserve rs; rs.next = rs.end = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
-    uint32_t n_seg = 0, n_rays = 0, n_nan = 0;
+    uint32_t n_seg = 0, n_rays = 0;
 
     for (;;) {
-        if (fetch_pixel(A, !have && !dead, px, dead)) { have = true; newpath = true; }
+        if (fetch_pixel(A, !have && !dead, px, dead, rs)) { have = true; newpath = true; }
         if (__ballot(!dead) == 0ull) break;
         if (have && newpath) { newpath = false; start_path(A, px, pt); n_rays++; }
         if (have) {
@@ -280,12 +319,12 @@ __global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
                 finished = shade<MOVING>(A, pt, best, best_t);
             }
             if (finished) {
-                if (finish_path(A, px, pt, n_nan)) have = false;
+                if (finish_path(A, px, pt)) have = false;
                 else newpath = true;
             }
         }
     }
-    flush_counters(A, n_seg, n_rays, n_nan, (unsigned long long)n_seg * A.sc.n, 0);
+    flush_counters(A, n_seg, n_rays, (unsigned long long)n_seg * A.sc.n, 0);
 }
 
 // ================================================================================================
@@ -327,6 +366,9 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 #define RTW_KU 1.4305115e-6f    /* 24 * 2^-24 */
 #ifndef RTW_S_HI
 #define RTW_S_HI 48u            /* lanes waiting in SHADE that trigger a SHADE step */
+#endif
+#ifndef RTW_BRANCHLESS_DESCEND
+#define RTW_BRANCHLESS_DESCEND 1   /* select form of the descend step: +2 % on the bench frame */
 #endif
 #ifndef RTW_SPLIT_SHADE
 #define RTW_SPLIT_SHADE 0       /* 1: hits are scattered in their own phase (HIT), apart from path start/end (SHADE).
@@ -417,6 +459,21 @@ template <class S>
 __device__ __forceinline__ int trav_descend(Trav &tr, S *stack, float e0, float x0, float e1, float x1, int c0, int c1) {
     const bool h0 = e0 <= x0 && x0 >= tr.lo_lim && e0 <= tr.hi_lim;
     const bool h1 = e1 <= x1 && x1 >= tr.lo_lim && e1 <= tr.hi_lim;
+#if RTW_BRANCHLESS_DESCEND
+    // select form: one predicated LDS write, one predicated LDS read, no nested exec-mask regions
+    const bool both = h0 && h1, none = !h0 && !h1;
+    const bool near0 = h0 && (!h1 || e0 <= e1);
+    const int nearc = near0 ? c0 : c1, farc = near0 ? c1 : c0;
+    if (both) stack[tr.sp * RTW_BLOCK + threadIdx.x] = (S)farc;
+    tr.sp += both ? 1u : 0u;
+    const bool pop = none && tr.sp != 0u;
+    int popped = 0;
+    if (pop) popped = (int)stack[(tr.sp - 1u) * RTW_BLOCK + threadIdx.x];
+    tr.sp -= pop ? 1u : 0u;
+    tr.node = none ? popped : nearc;
+    if (none && !pop) return PH_SHADE;
+    return tr.node < 0 ? PH_LEAF : PH_TRAV;
+#else
     if (h0 && h1) {
         const bool near0 = e0 <= e1;
         stack[tr.sp * RTW_BLOCK + threadIdx.x] = (S)(near0 ? c1 : c0);
@@ -427,6 +484,7 @@ __device__ __forceinline__ int trav_descend(Trav &tr, S *stack, float e0, float 
     if (h0) { tr.node = c0; return c0 < 0 ? PH_LEAF : PH_TRAV; }
     if (h1) { tr.node = c1; return c1 < 0 ? PH_LEAF : PH_TRAV; }
     return trav_pop(tr, stack);
+#endif
 }
 
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -480,7 +538,7 @@ __device__ __forceinline__ int trav_node(const DevBvh &bv, Trav &tr, int *stack)
 }
 
 #ifndef RTW_BVH_WAVES
-#define RTW_BVH_WAVES 5        /* min waves per SIMD the register allocator must leave room for */
+#define RTW_BVH_WAVES 4        /* min waves per SIMD the register allocator must leave room for */
 #endif
 template <bool MOVING, bool LDSN>
 __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KArgs A) {
@@ -498,11 +556,12 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
 
     int ph = PH_SHADE;
     bool have = false, inflight = false, newpath = false;
-    Pixel px; px.i = px.j = px.k = px.rng_base = px.s = 0; px.acc = mk(0, 0, 0);
+    Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
+    Reserve rs; rs.next = rs.end = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
     Trav tr; tr.node = 0; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
-    uint32_t n_seg = 0, n_rays = 0, n_nan = 0, n_nodes = 0, n_tests = 0;
+    uint32_t n_seg = 0, n_rays = 0, n_nodes = 0, n_tests = 0;
     bool path_done = false;                         // a finished path waits for PH_SHADE to bank it
     uint32_t c_steps[4] = { 0, 0, 0, 0 };           // wave-uniform (SGPR) census of the scheduler
     unsigned long long c_lanes[4] = { 0, 0, 0, 0 };
@@ -541,8 +600,9 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
             }
         } else if (run_shade) {
             c_steps[2]++; c_lanes[2] += nS;
+            // a. the closest-hit query this lane was waiting on is complete
+            bool need_unit = false;
             if (ph == PH_SHADE) {
-                // a. the closest-hit query this lane was waiting on missed everything
                 if (inflight) {
                     inflight = false;
                     n_seg++;
@@ -552,13 +612,18 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                     path_done = shade<MOVING>(A, pt, tr.best, tr.best_t);
 #endif
                 }
-                if (path_done) { path_done = false; if (finish_path(A, px, pt, n_nan)) have = false; else newpath = true; }
-                // b. next pixel (one atomic per wave for all lanes that need one)
-                bool exhausted = false;
-                if (fetch_pixel(A, !have, px, exhausted)) { have = true; newpath = true; }
+                if (path_done) { path_done = false; if (finish_path(A, px, pt)) have = false; else newpath = true; }
+                need_unit = !have;
+            }
+            // b. next work unit.  Executed by EVERY lane of the wave (not only the ones in SHADE): the wave's
+            //    reserve must stay wave-uniform, which it only does if all lanes run its bookkeeping.
+            bool exhausted = false;
+            const bool got = fetch_pixel(A, need_unit, px, exhausted, rs);
+            if (ph == PH_SHADE) {
+                if (got) { have = true; newpath = true; }
                 if (exhausted) ph = PH_DEAD;
                 if (have) {
-                    // c. next camera ray.  A lane whose path continues (split off: hit shaded here) keeps its ray.
+                    // c. next camera ray.  A lane whose path continues keeps its ray.
                     if (newpath) { newpath = false; start_path(A, px, pt); n_rays++; }
                     // d. start the next closest-hit query
                     if (A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
@@ -601,7 +666,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
         c_time[which] += __builtin_amdgcn_s_memtime() - t_begin;
 #endif
     }
-    flush_counters(A, n_seg, n_rays, n_nan, n_tests, n_nodes);
+    flush_counters(A, n_seg, n_rays, n_tests, n_nodes);
     if ((threadIdx.x & 63u) == 0) {
         for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[5 + k], (unsigned long long)c_steps[k]); atomicAdd(&A.stats[8 + k], c_lanes[k]); }
         atomicAdd(&A.stats[14], (unsigned long long)c_steps[3]); atomicAdd(&A.stats[15], c_lanes[3]);
@@ -625,6 +690,7 @@ static kernel_fn pick_kernel(bool moving, uint32_t accel, bool lds_nodes) {
 
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(pick_kernel(moving, accel, a.bvh.nodes16 != nullptr), dim3(grid), dim3(RTW_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(resolve_kernel, dim3((a.n_tiles * 64u + RTW_BLOCK - 1) / RTW_BLOCK), dim3(RTW_BLOCK), 0, stream, a);
 }
 
 uint32_t kernel_blocks_per_cu(bool moving, uint32_t accel, bool lds_nodes) {

@@ -39,6 +39,8 @@ struct rtw_ctx {
     unsigned long long *d_stats = nullptr;
     float *d_out = nullptr;
     size_t d_out_cap = 0;
+    float *d_samples = nullptr;          // per-sample radiance bank (see rtw_ctx_render)
+    size_t d_samples_cap = 0;
 };
 
 template <class T>
@@ -110,6 +112,7 @@ void rtw_ctx_destroy(rtw_ctx *c) {
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_samples) (void)hipFree(c->d_samples);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -201,12 +204,9 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     a.cam = *cam; a.sc = c->sc; a.bvh = c->bvh;
     if (p->flags & RTW_FLAG_GLOBAL_NODES) a.bvh.nodes16 = nullptr;
     a.width = p->width; a.height = p->height;
-    a.n_rows = rtw_part_rows(p->height, p->row_block, p->part_index, p->part_count);
+    const uint32_t n_rows = rtw_part_rows(p->height, p->row_block, p->part_index, p->part_count);
     a.row_block = p->row_block ? p->row_block : 1; a.part_index = p->part_index; a.part_count = p->part_count;
     a.tiles_x = (p->width + 7) / 8;
-    const uint64_t total = 64ull * a.tiles_x * ((a.n_rows + 7) / 8);
-    if (total >= (1ull << 32)) return RTW_E_INVALID;
-    a.total_work = (uint32_t)total;
     a.n_samples = sampler_count(p->sampler, p->samples, &a.s_root);
     if (a.n_samples == 0) return RTW_E_INVALID;
     a.sampler = p->sampler; a.integrator = p->integrator; a.depth = p->depth;
@@ -216,7 +216,33 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     std::memcpy(a.bg, c->bg, sizeof a.bg);
     a.queue = c->d_queue; a.stats = c->d_stats;
 
-    const size_t out_bytes = (size_t)a.n_rows * p->width * 3 * sizeof(float);
+    // Work units are (tile, chunk of samples, pixel): a pixel's samples are spread over ceil(n / chunk_len) units
+    // so that no lane owns more than chunk_len sequential paths (the slowest PIXEL used to set a ~50 ms tail).
+    // Every sample's radiance is banked in HBM and added in order by resolve_kernel: 12 B per camera ray
+    // (12.4 GB for 1920x1080x500) -- the image is rendered in bands of tile rows when that exceeds the budget.
+    uint32_t chunk_len = 4;          // tuned on the bench frame: 4-6 is the flat optimum (1: 13.5, 2: 17.0, 4: 17.9, 8: 17.3, 16: 16.8 Gsegments/s)
+    if (const char *e = getenv("RTW_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 4096) chunk_len = (uint32_t)v; }
+    if (chunk_len > a.n_samples) chunk_len = a.n_samples;
+    a.chunk_len = chunk_len;
+    a.n_chunks = (a.n_samples + chunk_len - 1) / chunk_len;
+    const uint64_t slots_per_tile_row = (uint64_t)a.tiles_x * a.n_chunks * 64ull * chunk_len;
+    uint64_t budget = 48ull << 30;
+    if (const char *e = getenv("RTW_SAMPLE_BUF_GB")) { double v = atof(e); if (v > 0.0) budget = (uint64_t)(v * (double)(1ull << 30)); }
+    uint64_t max_slots = budget / 12; if (max_slots > 0xFFFFFFF0ull) max_slots = 0xFFFFFFF0ull;
+    const uint32_t tile_rows = (n_rows + 7) / 8;
+    uint64_t band_tile_rows = max_slots / (slots_per_tile_row ? slots_per_tile_row : 1);
+    if (band_tile_rows == 0) return RTW_E_NOMEM;                  // one row of tiles does not fit the budget
+    if (band_tile_rows > tile_rows) band_tile_rows = tile_rows;
+    const size_t sample_bytes = (size_t)(band_tile_rows * slots_per_tile_row) * 12;
+    if (c->d_samples_cap < sample_bytes) {
+        if (c->d_samples) (void)hipFree(c->d_samples);
+        c->d_samples = nullptr; c->d_samples_cap = 0;
+        if (hipMalloc((void **)&c->d_samples, sample_bytes ? sample_bytes : 12) != hipSuccess) { (void)hipGetLastError(); return RTW_E_NOMEM; }
+        c->d_samples_cap = sample_bytes;
+    }
+    a.samples = c->d_samples;
+
+    const size_t out_bytes = (size_t)n_rows * p->width * 3 * sizeof(float);
     hipPointerAttribute_t attr;
     bool out_on_device = false;
     if (hipPointerGetAttributes(&attr, out_rgb) == hipSuccess) {
@@ -236,15 +262,22 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     // persistent grid: as many workgroups as the kernel's registers let be resident, capped by the work
     uint32_t per_cu = kernel_blocks_per_cu(c->sc.moving != 0, p->accel, c->bvh.nodes16 != nullptr && !(p->flags & RTW_FLAG_GLOBAL_NODES));
     if (const char *e = getenv("RTW_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = (uint32_t)v; }   // occupancy experiments
-    uint32_t grid = (uint32_t)c->n_cu * per_cu;
-    const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
-    if (grid > need) grid = need ? need : 1;
 
-    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 64, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    launch_render(a, c->sc.moving != 0, p->accel, grid, c->stream);
-    HIP_TRY(hipGetLastError());
+    for (uint32_t tr0 = 0; tr0 < tile_rows || tr0 == 0; tr0 += (uint32_t)band_tile_rows) {
+        const uint32_t tr1 = tr0 + (uint32_t)band_tile_rows < tile_rows ? tr0 + (uint32_t)band_tile_rows : tile_rows;
+        a.k_base = tr0 * 8; a.k_end = tr1 * 8 < n_rows ? tr1 * 8 : n_rows;
+        a.n_tiles = a.tiles_x * (tr1 - tr0);
+        a.total_work = a.n_tiles * a.n_chunks * 64u;              // < 2^32 by the slot bound above
+        uint32_t grid = (uint32_t)c->n_cu * per_cu;
+        const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
+        if (grid > need) grid = need ? need : 1;
+        HIP_TRY(hipMemsetAsync(c->d_queue, 0, 64, c->stream));
+        if (a.n_tiles) launch_render(a, c->sc.moving != 0, p->accel, grid, c->stream);
+        HIP_TRY(hipGetLastError());
+        if (tile_rows == 0) break;
+    }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     unsigned long long h_stats[16];
     HIP_TRY(hipMemcpyAsync(h_stats, c->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, c->stream));
@@ -256,7 +289,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
         std::memset(stats, 0, sizeof *stats);
         stats->camera_rays = h_stats[0]; stats->segments = h_stats[1];
         stats->sphere_tests = h_stats[2]; stats->node_tests = h_stats[3];
-        stats->nan_pixels = (uint32_t)h_stats[4]; stats->rows = a.n_rows;
+        stats->nan_pixels = (uint32_t)h_stats[4]; stats->rows = n_rows;
         stats->kernel_ms = ms;
         for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
         stats->phase_steps[3] = h_stats[14]; stats->phase_lanes[3] = h_stats[15];

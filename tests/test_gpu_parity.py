@@ -344,3 +344,26 @@ def test_c4_c5_full_size(gpu, which):
         assert (np.abs(a[rows] - ref).max(axis=2) > 1e-6).sum() <= 0.002 * 8 * 1920
     else:
         assert ulp_diff(a[rows], ref).max() <= 2
+
+
+def test_sample_bank_bands_and_chunk_lengths(gpu, monkeypatch):
+    """The per-sample radiance bank may be rendered in bands of tile rows (memory budget) and with any chunk
+    length (samples per work unit): neither changes a bit of the image."""
+    scene, cam, p = small_view(R.SCENE_C2, 200, 120, 37)
+    p.gamma, p.accel = 1.0, R.ACCEL_BVH
+    ref, st_ref = O.render(cam, scene, p)
+    gpu.set_scene(scene)
+    base, st = gpu.render(cam, p)
+    assert np.array_equal(base, ref) and st.segments == st_ref.segments
+    for chunk in ("1", "5", "37", "64"):
+        monkeypatch.setenv("RTW_CHUNK", chunk)
+        img, st = gpu.render(cam, p)
+        assert np.array_equal(img, ref) and st.camera_rays == 200 * 120 * 37, chunk
+    monkeypatch.delenv("RTW_CHUNK")
+    monkeypatch.setenv("RTW_SAMPLE_BUF_GB", "0.003")         # ~3 MiB: forces several bands (one tile row is 25*10*64*4*12 B = 0.73 MiB)
+    img, st = gpu.render(cam, p)
+    assert np.array_equal(img, ref) and st.segments == st_ref.segments
+    monkeypatch.setenv("RTW_SAMPLE_BUF_GB", "0.0005")        # less than one tile row: refused, not truncated
+    with pytest.raises(R.RtwError) as e:
+        gpu.render(cam, p)
+    assert e.value.status == -4
