@@ -12,7 +12,7 @@ on rank 0.  The frame is a fixed amount of work split over N GPUs, hence "scalin
 value = (closest-hit queries == "rays x bounces" of all ranks, counted exactly by the kernel) / wall time.
 
 The JSON line also carries
-  roofline      for the render kernel: ALGORITHMIC f32 flop (DESIGN.md "Roofline": 50/node visit,
+  roofline      for the render kernel (+ its resolve pass): ALGORITHMIC f32 flop (DESIGN.md "Roofline": 50/node visit,
                 17/exact sphere test, 120/segment) / mean kernel time (HIP events on the launch stream,
                 taken inside rtw_ctx_render) against the 157.3 TFLOP/s f32 vector peak.  The path is
                 VALU-bound by construction (12 B of HBM per pixel per frame); `hbm` gives the achieved
@@ -151,7 +151,7 @@ def main():
         flop = (nodes * F_NODE + tests * F_SPHERE + seg * F_SEGMENT) / args.steps / world   # per launch, per GPU
         achieved = flop / k_s / 1e12
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")   # PMC passes of this same command (scripts/profile_bench.sh)
         if os.path.exists(tpath) and world == 1 and not args.spp and args.accel == "bvh":
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         out = {
@@ -168,7 +168,7 @@ def main():
                        "segments_per_camera_ray": round(seg / max(rays, 1), 4)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS, 5), "traffic": traffic,
-                         "kernel": "rtw::render_kernel<moving=false, accel=%s>" % args.accel,
+                         "kernel": "rtw::render_%s<moving=false> + rtw::resolve_kernel (timed together: HIP events around both)" % args.accel,
                          "kernel_ms": round(k_s * 1e3, 3),
                          "algorithmic_flop_per_launch": flop,
                          "scheduler_census_rank0": {n: {"wave_steps": steps3[k] // args.steps,
@@ -176,8 +176,9 @@ def main():
                                                         for k, n in enumerate(("traverse", "leaf", "shade", "hit"))},
                          "units_per_launch": {"segments": seg / args.steps / world, "node_visits": nodes / args.steps / world,
                                               "sphere_tests": tests / args.steps / world},
-                         "hbm": {"achieved": round(H * W * 12 / world / k_s / 1e9, 4), "peak": 8000.0, "unit": "GB/s",
-                                 "note": "framebuffer write only: 12 B/pixel/frame; the path is not HBM-bound"}},
+                         "hbm": {"achieved": round((H * W * 12 + rays / args.steps * 24) / world / k_s / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
+                                 "note": "algorithmic bytes: 12 B per camera ray written to the per-sample bank + read back "
+                                         "by the in-order resolve, + 12 B/pixel framebuffer; the path is not HBM-bound"}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(R, scene, cam, p)
