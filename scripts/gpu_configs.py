@@ -1,0 +1,27 @@
+"""Time every BASELINE config at full size with both closest-hit strategies (one GPU); prints a markdown table."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rtw_amd as R
+r = R.Renderer(0)
+rows = []
+cfgs = [("C1 3 spheres", R.SCENE_C1, R.SCENE_C1, None), ("C2 Book-1 final", R.SCENE_C2, R.SCENE_C2, None),
+        ("C3 Book-1 final (bench)", R.SCENE_C2, R.SCENE_C5, 0.0), ("C4 dielectric-heavy", R.SCENE_C4, R.SCENE_C4, None),
+        ("C5 motion blur + texture", R.SCENE_C5, R.SCENE_C5, None)]
+for name, scene_id, view_id, shutter in cfgs:
+    sc = R.Scene.generate(scene_id); cam, p = R.default_view(view_id)
+    if shutter is not None: cam.shutter = shutter
+    out = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device="cuda:0")
+    r.set_scene(sc, cam.time0, cam.time0 + cam.shutter)
+    res = {}
+    for accel in (R.ACCEL_BVH, R.ACCEL_BRUTE):
+        p.accel = accel
+        r.render(cam, p, out=out.data_ptr())
+        best = None
+        for _ in range(3):
+            _, st = r.render(cam, p, out=out.data_ptr())
+            if best is None or st.kernel_ms < best.kernel_ms: best = st
+        res[accel] = best
+    b, f = res[R.ACCEL_BVH], res[R.ACCEL_BRUTE]
+    print(f"| {name} | {sc.n_spheres} | {p.width}x{p.height}x{b.camera_rays // (p.width * p.height)} | {p.depth} | {b.segments / b.camera_rays:.2f} | "
+          f"{b.kernel_ms:.2f} | {b.segments / b.kernel_ms / 1e6:.2f} | {b.camera_rays / b.kernel_ms / 1e6:.2f} | {f.kernel_ms:.2f} | {f.segments / f.kernel_ms / 1e6:.2f} |", flush=True)
