@@ -91,11 +91,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available() and R.device_count() > 0, "bench.py needs the MI355X: there is no CPU path"
+    backend = os.environ.get("RTW_BENCH_BACKEND", "nccl")       # "gloo": rehearse the N > 1 path on a 1-GPU box (tests only)
+    if os.environ.get("RTW_BENCH_SINGLE_DEVICE"):               # ... with every rank on cuda:0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     scene = R.Scene.generate(R.SCENE_C2, 42)
     cam, p = R.default_view(R.SCENE_C5)          # 1920 x 1080 x 500 spp x depth 50 framing
@@ -107,7 +113,7 @@ def main():
         p.samples = args.spp
     H, W = p.height, p.width
 
-    r = R.Renderer(local_rank)
+    r = R.Renderer(local_rank)                                  # one rtw_ctx per process == per GPU
     r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
     local = torch.zeros((par.max_rows(H, world), W, 3), dtype=torch.float32, device=dev)
@@ -131,14 +137,14 @@ def main():
     fence()
     t0 = time.perf_counter()
     seg = rays = nodes = tests = 0
-    steps3, lanes3 = [0, 0, 0, 0], [0, 0, 0, 0]
+    steps3, lanes3 = [0, 0, 0], [0, 0, 0]
     kernel_ms = 0.0
     frame = None
     for _ in range(args.steps):
         frame, st = step()
         seg += st.segments; rays += st.camera_rays; nodes += st.node_tests; tests += st.sphere_tests
         kernel_ms += st.kernel_ms
-        for k in range(4):
+        for k in range(3):
             steps3[k] += st.phase_steps[k]; lanes3[k] += st.phase_lanes[k]
     fence()
     elapsed = time.perf_counter() - t0
@@ -173,7 +179,7 @@ def main():
                          "algorithmic_flop_per_launch": flop,
                          "scheduler_census_rank0": {n: {"wave_steps": steps3[k] // args.steps,
                                                             "simd_efficiency": round(lanes3[k] / max(1, 64 * steps3[k]), 4)}
-                                                        for k, n in enumerate(("traverse", "leaf", "shade", "hit"))},
+                                                        for k, n in enumerate(("traverse", "leaf", "shade"))},
                          "units_per_launch": {"segments": seg / args.steps / world, "node_visits": nodes / args.steps / world,
                                               "sphere_tests": tests / args.steps / world},
                          "hbm": {"achieved": round((H * W * 12 + rays / args.steps * 24) / world / k_s / 1e9, 3), "peak": 8000.0, "unit": "GB/s",

@@ -26,7 +26,7 @@ pub struct RtwParams { pub width: u32, pub height: u32, pub samples: u32, pub de
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]
 pub struct RtwStats { pub camera_rays: u64, pub segments: u64, pub sphere_tests: u64, pub node_tests: u64,
     pub nan_pixels: u32, pub rows: u32, pub kernel_ms: f32, pub total_ms: f32,
-    pub phase_steps: [u64; 4], pub phase_lanes: [u64; 4] }
+    pub phase_steps: [u64; 3], pub phase_lanes: [u64; 3] }
 
 #[repr(C)] pub struct RtwCtx { _private: [u8; 0] }
 

@@ -1,0 +1,94 @@
+// render_scene.cpp -- what the reference's `main` / test functions do (build a scene, `Viewport::new_from_res`,
+// render, `write_img_f32`; Rust/src/main.rs:61-87, Rust/src/viewport/material_tests.rs:105-167), written
+// against the C ABI of include/rtw.h only.  Compiled by `make -C raytracing-in-a-weekend_amd/csrc example`.
+//
+//   render_scene --scene metal --out metal_test.png
+//   render_scene --json scene.json --width 400 --height 225 --spp 100 --depth 10 --out scene.png
+#include "rtw.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static int die(const char *what, int rc) { std::fprintf(stderr, "%s: %s\n", what, rtw_strerror(rc)); return 1; }
+
+int main(int argc, char **argv) {
+    std::string scene_name = "metal", json_path, out = "out.png", dump_json;
+    uint32_t width = 0, height = 0, spp = 0, depth = 0, accel = RTW_ACCEL_BVH;
+    uint64_t seed = 1;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--scene") scene_name = next();
+        else if (a == "--json") json_path = next();
+        else if (a == "--dump-json") dump_json = next();
+        else if (a == "--out") out = next();
+        else if (a == "--width") width = (uint32_t)std::atoi(next());
+        else if (a == "--height") height = (uint32_t)std::atoi(next());
+        else if (a == "--spp") spp = (uint32_t)std::atoi(next());
+        else if (a == "--depth") depth = (uint32_t)std::atoi(next());
+        else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
+        else if (a == "--accel") accel = std::string(next()) == "brute" ? RTW_ACCEL_BRUTE : RTW_ACCEL_BVH;
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    uint32_t which = scene_name == "c1" ? RTW_SCENE_C1_THREE_SPHERES : scene_name == "book1" ? RTW_SCENE_C2_BOOK1_FINAL
+                   : scene_name == "dielectric" ? RTW_SCENE_C4_DIELECTRIC : scene_name == "motion" ? RTW_SCENE_C5_MOTION_CHECKER
+                   : RTW_SCENE_METAL_TEST;
+
+    std::vector<RtwSphere> spheres; std::vector<RtwTexture> textures; std::vector<float> texels;
+    uint32_t ns = 0, nt = 0, nx = 0;
+    int rc;
+    if (!json_path.empty()) {                      // Scene::try_from(json) (Rust/src/viewport.rs:181-205)
+        FILE *f = std::fopen(json_path.c_str(), "rb");
+        if (!f) { std::perror(json_path.c_str()); return 1; }
+        std::string text; char buf[65536]; size_t n;
+        while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+        std::fclose(f);
+        if ((rc = rtw_scene_from_json(text.data(), text.size(), nullptr, 0, &ns, nullptr, 0, &nt, nullptr, 0, &nx))) return die("scene json", rc);
+        spheres.resize(ns ? ns : 1); textures.resize(nt ? nt : 1); texels.resize(3 * (nx ? nx : 1));
+        if ((rc = rtw_scene_from_json(text.data(), text.size(), spheres.data(), ns, &ns, textures.data(), nt, &nt, texels.data(), nx, &nx))) return die("scene json", rc);
+    } else {
+        if ((rc = rtw_scene_generate(which, 42, nullptr, 0, &ns, nullptr, 0, &nt, nullptr, 0, &nx))) return die("scene", rc);
+        spheres.resize(ns ? ns : 1); textures.resize(nt ? nt : 1); texels.resize(3 * (nx ? nx : 1));
+        if ((rc = rtw_scene_generate(which, 42, spheres.data(), ns, &ns, textures.data(), nt, &nt, texels.data(), nx, &nx))) return die("scene", rc);
+    }
+    RtwScene scene{ spheres.data(), textures.data(), texels.data(), ns, nt, nx, { 0, 0, 0 } };
+    if (!dump_json.empty()) {                       // Into<JsonValue> for Scene
+        size_t n = rtw_scene_to_json(&scene, nullptr, 0);
+        std::string text(n + 1, '\0');
+        rtw_scene_to_json(&scene, &text[0], n + 1);
+        FILE *f = std::fopen(dump_json.c_str(), "wb");
+        if (f) { std::fwrite(text.data(), 1, n, f); std::fclose(f); }
+    }
+
+    RtwCamera cam; RtwParams p;
+    if ((rc = rtw_scene_default_view(which, &cam, &p))) return die("view", rc);
+    if (width && height) {                          // Viewport::new_from_res(width, height, ..) keeping the view's origin/direction
+        // the default views of the generators use the reference's default camera except for the Book-1 framing
+        const bool book1 = which != RTW_SCENE_C1_THREE_SPHERES && which != RTW_SCENE_METAL_TEST;
+        const float from[3] = { 13, 2, 3 }, len = 13.4907375f, dir[3] = { -13 / len, -2 / len, -3 / len }, vfov = 20, lens = 0.05f;
+        uint32_t h = 0;
+        const float keep_time0 = cam.time0, keep_shutter = cam.shutter;
+        rc = book1 ? rtw_viewport_new_from_res(width, height, &vfov, from, dir, nullptr, &lens, &cam, &h)
+                   : rtw_viewport_new_from_res(width, height, nullptr, nullptr, nullptr, nullptr, nullptr, &cam, &h);
+        if (rc) return die("viewport", rc);
+        cam.time0 = keep_time0; cam.shutter = keep_shutter;
+        p.width = width; p.height = h;
+    }
+    if (spp) p.samples = spp;
+    if (depth) p.depth = depth;
+    p.accel = accel; p.seed = seed;
+
+    std::vector<float> img((size_t)3 * p.width * p.height);
+    RtwStats st;
+    if ((rc = rtw_render(&cam, &scene, &p, img.data(), &st))) return die("rtw_render", rc);
+    std::printf("%u spheres, %ux%u, %llu camera rays, %llu segments, %.3f ms on the GPU (%.2f Gsegments/s), %u NaN pixels\n",
+                ns, p.width, p.height, (unsigned long long)st.camera_rays, (unsigned long long)st.segments, st.kernel_ms,
+                st.segments / (st.kernel_ms * 1e6), st.nan_pixels);
+    const bool ppm = out.size() > 4 && out.substr(out.size() - 4) == ".ppm";
+    rc = ppm ? rtw_write_ppm_f32(out.c_str(), img.data(), p.width, p.height) : rtw_write_png_f32(out.c_str(), img.data(), p.width, p.height);
+    if (rc) return die(out.c_str(), rc);
+    return 0;
+}

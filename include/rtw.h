@@ -161,11 +161,10 @@ typedef struct RtwStats {
     uint32_t rows;           /* rows written by this call                             */
     float    kernel_ms;      /* device time of the render kernels (hipEvent)          */
     float    total_ms;       /* host wall time of the call                            */
-    /* BVH kernel scheduler census: wave-level steps executed per phase (0 traverse, 1 leaf, 2 shade =
-     * path start/end, 3 hit = scatter) and the lanes that were live in them; lanes / (64 * steps) is the
-     * SIMD efficiency of a phase. */
-    uint64_t phase_steps[4];
-    uint64_t phase_lanes[4];
+    /* BVH kernel scheduler census: wave-level steps executed per phase (0 traverse, 1 leaf, 2 shade)
+     * and the lanes that were live in them; lanes / (64 * steps) is the SIMD efficiency of a phase. */
+    uint64_t phase_steps[3];
+    uint64_t phase_lanes[3];
 } RtwStats;
 
 typedef struct rtw_ctx rtw_ctx;

@@ -370,22 +370,8 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 #ifndef RTW_BRANCHLESS_DESCEND
 #define RTW_BRANCHLESS_DESCEND 1   /* select form of the descend step: +2 % on the bench frame */
 #endif
-#ifndef RTW_SPLIT_SHADE
-#define RTW_SPLIT_SHADE 0       /* 1: hits are scattered in their own phase (HIT), apart from path start/end (SHADE).
-                                   Measured on the bench frame: 10.8 vs 14.9 Gsegments/s -- the extra queueing costs more
-                                   than the denser steps save, so it stays off (kept for experiments). */
-#endif
-#ifndef RTW_H_HI
-#define RTW_H_HI 40u            /* lanes waiting in HIT that trigger a HIT step */
-#endif
 #ifndef RTW_TRAV_UNROLL
-#define RTW_TRAV_UNROLL 3       /* max node visits per scheduling decision */
-#endif
-#ifndef RTW_T_KEEP
-#define RTW_T_KEEP 1u           /* a burst ends early when fewer lanes than this are still traversing */
-#endif
-#ifndef RTW_L_HI
-#define RTW_L_HI 0u             /* lanes waiting in LEAF that pre-empt TRAVERSE (0: the larger queue runs) */
+#define RTW_TRAV_UNROLL 3       /* node visits per scheduling decision (1: 13.2, 2: 14.4, 3: 14.9, 4: 14.2 Gsegments/s) */
 #endif
 #ifndef RTW_T_LO
 #define RTW_T_LO 6u             /* below this many lanes in TRAVERSE and in LEAF, SHADE runs anyway */
@@ -402,7 +388,7 @@ struct Trav {                // traversal state of one lane
     float tau_t, lo_lim, hi_lim;
 };
 
-enum { PH_SHADE = 0, PH_TRAV = 1, PH_LEAF = 2, PH_DEAD = 3, PH_HIT = 4 };
+enum { PH_SHADE = 0, PH_TRAV = 1, PH_LEAF = 2, PH_DEAD = 3 };
 
 // Begin a closest-hit query: big spheres, per-ray constants, root.  Returns the phase to enter.
 template <bool MOVING>
@@ -562,55 +548,37 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
     Trav tr; tr.node = 0; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
     uint32_t n_seg = 0, n_rays = 0, n_nodes = 0, n_tests = 0;
-    bool path_done = false;                         // a finished path waits for PH_SHADE to bank it
-    uint32_t c_steps[4] = { 0, 0, 0, 0 };           // wave-uniform (SGPR) census of the scheduler
-    unsigned long long c_lanes[4] = { 0, 0, 0, 0 };
+    bool path_done = false;                         // a finished path waits for the next SHADE step to bank it
+    uint32_t c_steps[3] = { 0, 0, 0 };              // wave-uniform (SGPR) census of the scheduler
+    unsigned long long c_lanes[3] = { 0, 0, 0 };
 #ifdef RTW_STAMP
-    unsigned long long c_time[4] = { 0, 0, 0, 0 };
+    unsigned long long c_time[3] = { 0, 0, 0 };
 #endif
 
     for (;;) {
         // ---- scheduler ---------------------------------------------------------------------------
-        // Phases: TRAVERSE (inner-node visits), LEAF (one exact sphere test), HIT (scatter at the closest
-        // hit: Material::on_hit, then set up the next query) and SHADE (everything that ends or starts a
-        // path: sky/background for a miss, add the path to the pixel, resolve + next pixel, camera ray,
-        // set up the query).  HIT and SHADE are the expensive steps (several hundred instructions): each
-        // runs when enough lanes have piled up in it (RTW_H_HI / RTW_S_HI) or when little traversal work
-        // is left to hide behind (RTW_T_LO); otherwise the larger of the two traversal queues runs.
+        // SHADE is the expensive step (several hundred instructions): it runs when enough lanes have piled up
+        // in it (RTW_S_HI) or when little traversal work is left to hide behind (RTW_T_LO); otherwise the
+        // larger of the two traversal queues runs.
         const uint32_t nT = (uint32_t)__popcll(__ballot(ph == PH_TRAV));
         const uint32_t nL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
         const uint32_t nS = (uint32_t)__popcll(__ballot(ph == PH_SHADE));
-        const uint32_t nH = (uint32_t)__popcll(__ballot(ph == PH_HIT));
-        if ((nT | nL | nS | nH) == 0u) break;                // every lane is PH_DEAD
-        bool run_hit = nH >= RTW_H_HI, run_shade = nS >= RTW_S_HI;
-        if (!run_hit && !run_shade && nT < RTW_T_LO && nL < RTW_T_LO) { run_hit = nH >= nS && nH > 0u; run_shade = !run_hit && nS > 0u; }
-        if (run_hit && run_shade) { if (nH >= nS) run_shade = false; else run_hit = false; }
-        const bool run_leaf = RTW_L_HI ? (nL >= RTW_L_HI || nT == 0u) : (nL > nT);
+        if ((nT | nL | nS) == 0u) break;                     // every lane is PH_DEAD
+        const bool run_shade = nS >= RTW_S_HI || (nT < RTW_T_LO && nL < RTW_T_LO && nS > 0u);
+        const bool run_leaf = nL > nT;
 #ifdef RTW_STAMP
         const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-        const int which = run_hit ? 3 : (run_shade ? 2 : (run_leaf ? 1 : 0));
+        const int which = run_shade ? 2 : (run_leaf ? 1 : 0);
 #endif
-        bool want_query = false;                             // lanes that start a closest-hit query this trip
-        if (run_hit) {
-            c_steps[3]++; c_lanes[3] += nH;
-            if (ph == PH_HIT) {
-                n_seg++;
-                if (shade_hit<MOVING>(A, pt, tr.best, tr.best_t)) { path_done = true; inflight = false; ph = PH_SHADE; }
-                else want_query = true;
-            }
-        } else if (run_shade) {
+        if (run_shade) {
             c_steps[2]++; c_lanes[2] += nS;
-            // a. the closest-hit query this lane was waiting on is complete
+            // a. the closest-hit query this lane was waiting on is complete: scatter, or end the path
             bool need_unit = false;
             if (ph == PH_SHADE) {
                 if (inflight) {
                     inflight = false;
                     n_seg++;
-#if RTW_SPLIT_SHADE
-                    shade_miss(A, pt); path_done = true;                   // hits went to PH_HIT
-#else
                     path_done = shade<MOVING>(A, pt, tr.best, tr.best_t);
-#endif
                 }
                 if (path_done) { path_done = false; if (finish_path(A, px, pt)) have = false; else newpath = true; }
                 need_unit = !have;
@@ -623,26 +591,28 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                 if (got) { have = true; newpath = true; }
                 if (exhausted) ph = PH_DEAD;
                 if (have) {
-                    // c. next camera ray.  A lane whose path continues keeps its ray.
+                    // c. next camera ray (a lane whose path continues keeps its scattered ray)
                     if (newpath) { newpath = false; start_path(A, px, pt); n_rays++; }
                     // d. start the next closest-hit query
                     if (A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
                         pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
                         path_done = true;                                  // banked on the next SHADE trip
-                    } else want_query = true;
+                    } else {
+                        ph = trav_begin<MOVING>(A, pt, tr, n_tests);
+                        inflight = true;
+                    }
                 }
             }
         } else if (!run_leaf) {
-            c_steps[0]++; c_lanes[0] += nT;
-            // Up to RTW_TRAV_UNROLL node visits per scheduling decision, while at least RTW_T_KEEP lanes are
-            // still traversing: the scheduler's ballots and branches are paid once per burst, and lanes
-            // that left TRAVERSE (leaf reached / query done) sit out only the rest of the burst.
+            // RTW_TRAV_UNROLL node visits per scheduling decision: the scheduler's ballots and branches are
+            // paid once per burst; lanes that leave TRAVERSE (leaf reached / query done) sit out the rest of it.
+            uint32_t live = nT;
             for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
+                c_steps[0]++; c_lanes[0] += live;
                 if (ph == PH_TRAV) { n_nodes++; ph = LDSN ? trav_node_lds(lnodes, tr, (short *)stack) : trav_node(A.bvh, tr, (int *)stack); }
                 if (u + 1 >= RTW_TRAV_UNROLL) break;
-                const uint32_t live = (uint32_t)__popcll(__ballot(ph == PH_TRAV));
-                if (live < RTW_T_KEEP) break;
-                c_steps[0]++; c_lanes[0] += live;                // census of the extra visit
+                live = (uint32_t)__popcll(__ballot(ph == PH_TRAV));
+                if (live == 0u) break;
             }
         } else {
             c_steps[1]++; c_lanes[1] += nL;
@@ -654,12 +624,6 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                 ph = trav_pop(tr, stack);
             }
         }
-        // one copy of the query set-up (big spheres + per-ray constants) for both expensive phases
-        if (run_hit || run_shade) {
-            if (want_query) { ph = trav_begin<MOVING>(A, pt, tr, n_tests); inflight = true; }
-        }
-        // a query that just completed with a hit goes to HIT, a miss (or a banked path) waits in SHADE
-        if (RTW_SPLIT_SHADE && ph == PH_SHADE && inflight && tr.best >= 0) ph = PH_HIT;
 #ifdef RTW_STAMP
         // diagnostic build only: wave-ticks per phase (s_memtime), written to stats[11..13]
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -669,9 +633,8 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
     flush_counters(A, n_seg, n_rays, n_tests, n_nodes);
     if ((threadIdx.x & 63u) == 0) {
         for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[5 + k], (unsigned long long)c_steps[k]); atomicAdd(&A.stats[8 + k], c_lanes[k]); }
-        atomicAdd(&A.stats[14], (unsigned long long)c_steps[3]); atomicAdd(&A.stats[15], c_lanes[3]);
 #ifdef RTW_STAMP
-        for (int k = 0; k < 3; k++) atomicAdd(&A.stats[11 + k], c_time[k] + (k == 2 ? c_time[3] : 0ull));
+        for (int k = 0; k < 3; k++) atomicAdd(&A.stats[11 + k], c_time[k]);
 #endif
     }
 }

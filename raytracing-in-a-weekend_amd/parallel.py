@@ -35,10 +35,16 @@ def gather_frame(local: torch.Tensor, height: int, width: int, rank: int, world:
     [H][W][3] frame on rank 0, None elsewhere."""
     if world <= 1:
         return local[:height]
+    device = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()          # rehearsal of the N > 1 path without RCCL (tests): gloo gathers host tensors
     bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
     dist.gather(local, gather_list=bufs, dst=0, group=group)
     if rank != 0:
         return None
+    if bufs[0].device != device:
+        bufs = [b.to(device) for b in bufs]
+        local = local.to(device)
     frame = torch.empty((height, width, 3), dtype=local.dtype, device=local.device)
     for r in range(world):
         rows = rows_of(height, r, world, row_block)
@@ -61,7 +67,7 @@ def reduce_counters(values: List[float], world: int, device, group=None) -> List
     """Sum per-rank counters (segments, camera rays) for reporting; a tiny all-reduce outside the data path."""
     if world <= 1:
         return list(values)
-    t = torch.tensor(values, dtype=torch.float64, device=device)
+    t = torch.tensor(values, dtype=torch.float64, device="cpu" if dist.get_backend(group) == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return [float(x) for x in t.cpu()]
 
@@ -69,6 +75,6 @@ def reduce_counters(values: List[float], world: int, device, group=None) -> List
 def max_over_ranks(value: float, world: int, device, group=None) -> float:
     if world <= 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend(group) == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.cpu()[0])

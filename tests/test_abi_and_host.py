@@ -40,7 +40,7 @@ def test_pod_sizes_match_header():
     assert C.sizeof(R.RtwSphere) == 80
     assert C.sizeof(R.RtwTexture) == 16
     assert C.sizeof(R.RtwParams) == 72
-    assert C.sizeof(R.RtwStats) == 112
+    assert C.sizeof(R.RtwStats) == 96
     assert C.sizeof(R.RtwScene) == 48
 
 
