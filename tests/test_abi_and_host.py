@@ -195,3 +195,13 @@ def test_png_and_ppm_writers(tmp_path):
     assert tok[:4] == ["P3", "5", "7", "255"]
     want = (255 * np.clip(img, 0, 1).astype(np.float64)).astype(np.int32)       # RGB.cpp:16-20 truncation
     assert np.array_equal(np.array(tok[4:], np.int32).reshape(7, 5, 3), want)
+
+
+def test_missing_hip_library_fails_loudly():
+    """The product has no CPU fallback: without librtw_hip.so the package refuses to work (ImportError)."""
+    import subprocess, sys
+    code = ("import os, sys; os.environ['RTW_HIP_LIB'] = '/nonexistent/librtw_hip.so'; sys.path.insert(0, %r);\n"
+            "import rtw_amd as R\n"
+            "try:\n    R.lib(); print('LOADED')\nexcept ImportError as e:\n    print('IMPORTERROR', 'no CPU fallback' in str(e))\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "IMPORTERROR True" in out.stdout, out.stdout + out.stderr
