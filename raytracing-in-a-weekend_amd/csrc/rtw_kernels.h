@@ -39,6 +39,7 @@ struct KArgs {
     uint32_t n_samples;           // rays per pixel actually traced (sampler-dependent)
     uint32_t s_root;              // strata per axis (STRATIFIED / CENTRES)
     uint32_t sampler, integrator, depth;
+    uint32_t has_textures;        // any sphere with an image texture (selects the generic kernel)
     uint32_t seed_lo, seed_hi;
     float inv_gamma, mint, maxt;
     float bg[3];
@@ -50,6 +51,6 @@ struct KArgs {
 // accel: RTW_ACCEL_BRUTE, RTW_ACCEL_BVH; the BVH launch picks the LDS-resident variant when a.bvh.nodes16 != null
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream);
 // Resident workgroups per CU for the kernel variant (occupancy API), >= 1.
-uint32_t kernel_blocks_per_cu(bool moving, uint32_t accel, bool lds_nodes);
+uint32_t kernel_blocks_per_cu(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes);
 
 } // namespace rtw

@@ -31,6 +31,12 @@ namespace rtw {
 // shared pieces
 // ================================================================================================
 
+// SPEC == 1 is the specialisation for the common configuration -- ray_color_gradient, render_row sampler, depth >= 1,
+// no image textures (every BASELINE config but C5's textured ground): the integrator/sampler switches fold
+// away at compile time.  SPEC == 0 reads them from the (wave-uniform) kernel arguments.
+template <int SPEC> __device__ __forceinline__ uint32_t integ(const KArgs &A) { return SPEC ? (uint32_t)RTW_INTEGRATOR_GRADIENT : A.integrator; }
+template <int SPEC> __device__ __forceinline__ uint32_t samp(const KArgs &A) { return SPEC ? (uint32_t)RTW_SAMPLER_ROW : A.sampler; }
+
 struct Pixel {            // the work unit a lane owns: a run of consecutive samples of one pixel
     uint32_t i, j;        // column, image row
     uint32_t rng_base;    // hash of (seed, pixel)
@@ -94,6 +100,7 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
 }
 
 // Camera ray of sample px.s (the sampler loops of viewport.rs / Rust2 viewport.rs).
+template <int SPEC>
 __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path &pt) {
     const v3 cam_o = ld3(A.cam.origin), p00 = ld3(A.cam.pixel00), du = ld3(A.cam.delta_u), dv = ld3(A.cam.delta_v);
     pt.rng = rng_start(px.rng_base, px.s);
@@ -101,12 +108,12 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
     // (single assignment of pt.o / pt.d / pt.tm at the end: stores to different members on different
     //  branches get "sunk" into a phi of pointers by the optimiser, which forces the path state into scratch)
     v3 o, d; float tm = 0.0f;
-    if (A.sampler == RTW_SAMPLER_NO_RAND) {                  // viewport.rs:498-503
+    if (samp<SPEC>(A) == RTW_SAMPLER_NO_RAND) {                  // viewport.rs:498-503
         o = cam_o;
         d = (p00 + du * (float)px.i) + dv * (float)px.j;
     } else {
         float jx, jy, rx, ry;
-        if (A.sampler == RTW_SAMPLER_CENTRES) {              // Rust2/src/viewport.rs:92-104
+        if (samp<SPEC>(A) == RTW_SAMPLER_CENTRES) {              // Rust2/src/viewport.rs:92-104
             const uint32_t kx = px.s / A.s_root, ly = px.s % A.s_root;
             jx = ((float)px.i + ((float)kx + 0.5f) / (float)A.s_root) / (float)A.width;
             jy = ((float)px.j + ((float)ly + 0.5f) / (float)A.s_root) / (float)A.height;
@@ -115,7 +122,7 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
         } else {
             random_in_unit_disk(pt.rng, rx, ry);             // always drawn (viewport.rs:288)
             o = cam_o + (ld3(A.cam.u) * rx + ld3(A.cam.v) * ry) * A.cam.lens_radius;
-            if (A.sampler == RTW_SAMPLER_ROW) {              // viewport.rs:290-297
+            if (samp<SPEC>(A) == RTW_SAMPLER_ROW) {              // viewport.rs:290-297
                 jx = (float)px.i + rng_f32(pt.rng);
                 jy = (float)px.j + rng_f32(pt.rng);
                 tm = A.cam.time0 + A.cam.shutter * rng_f32(pt.rng);
@@ -131,17 +138,18 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
 }
 
 // ray_color_* when the closest-hit query found nothing: sky / background ends the path.
+template <int SPEC>
 __device__ __forceinline__ void shade_miss(const KArgs &A, Path &pt) {
     v3 miss;
-    if (A.integrator == RTW_INTEGRATOR_BG_COLOR || A.integrator == RTW_INTEGRATOR_RUST2) miss = ld3(A.bg);
-    else if (A.integrator == RTW_INTEGRATOR_FLAG) miss = mk(0.0f, 0.0f, 1.0f);
+    if (integ<SPEC>(A) == RTW_INTEGRATOR_BG_COLOR || integ<SPEC>(A) == RTW_INTEGRATOR_RUST2) miss = ld3(A.bg);
+    else if (integ<SPEC>(A) == RTW_INTEGRATOR_FLAG) miss = mk(0.0f, 0.0f, 1.0f);
     else miss = sky_gradient(pt.d);
     pt.L = pt.L + miss * pt.thr;
 }
 
 // One step of ray_color_* at the closest hit (best >= 0, best_t).  Returns true when the path is finished
 // (pt.L is then its radiance).
-template <bool MOVING>
+template <bool MOVING, int SPEC>
 __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, float best_t) {
     const DevScene &sc = A.sc;
     f4 g = sc.geom[best];
@@ -150,16 +158,16 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, fl
     const v3 point = pt.o + pt.d * best_t;                   // r.at(x)
     const v3 normal = unit(point - c);                       // sphere.rs:127
     const DevMat mat = sc.mat[best];
-    if (A.integrator == RTW_INTEGRATOR_NORMAL) {             // C++/src/tests.cpp:91
+    if (integ<SPEC>(A) == RTW_INTEGRATOR_NORMAL) {             // C++/src/tests.cpp:91
         pt.L = mk(normal.x + 1.0f, normal.y + 1.0f, normal.z + 1.0f) * 0.5f;
         return true;
     }
-    if (A.integrator == RTW_INTEGRATOR_FLAG && mat.metallicness != 1.0f) {
+    if (integ<SPEC>(A) == RTW_INTEGRATOR_FLAG && mat.metallicness != 1.0f) {
         pt.L = mk(1.0f, 1.0f, 0.0f) * pt.thr;                // glass_tests.rs:35-37
         return true;
     }
-    const v3 cm = sphere_albedo(sc, mat, normal);
-    if (A.integrator == RTW_INTEGRATOR_RUST2) {              // Rust2/src/viewport/ray_color.rs:17-31, front-to-back
+    const v3 cm = SPEC ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
+    if (integ<SPEC>(A) == RTW_INTEGRATOR_RUST2) {              // Rust2/src/viewport/ray_color.rs:17-31, front-to-back
         const v3 nd2 = on_hit_rust2(mat, normal, pt.d, pt.rng);
         pt.L = pt.L + ld3(mat.emitted) * pt.thr;
         pt.thr = pt.thr * cm;
@@ -170,7 +178,7 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, fl
     }
     float cos_theta;
     const v3 nd = on_hit(mat, normal, pt.d, pt.rng, cos_theta);
-    if (A.integrator == RTW_INTEGRATOR_BG_COLOR) {           // ray_color.rs:64-88, front-to-back
+    if (integ<SPEC>(A) == RTW_INTEGRATOR_BG_COLOR) {           // ray_color.rs:64-88, front-to-back
         // lambertian_scatter_pdf (materials.rs:5-13); pdf == 0 makes the reference's `color * pdf / pdf` a 0/0
         const float pdf = cos_theta > 0.0f ? cos_theta * 0.318309886183790671538f : 0.0f;
         if (mat.metallicness != 1.0f && !(pdf > 0.0f)) pt.poison = true;
@@ -180,16 +188,16 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, fl
     pt.o = point; pt.d = nd;
     pt.k++;
     if (pt.k >= A.depth) {                                   // depth exhausted: the innermost call returns black
-        if (A.integrator != RTW_INTEGRATOR_BG_COLOR) pt.L = mk(0, 0, 0);
+        if (integ<SPEC>(A) != RTW_INTEGRATOR_BG_COLOR) pt.L = mk(0, 0, 0);
         return true;
     }
     return false;
 }
 
-template <bool MOVING>
+template <bool MOVING, int SPEC>
 __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float best_t) {
-    if (best < 0) { shade_miss(A, pt); return true; }
-    return shade_hit<MOVING>(A, pt, best, best_t);
+    if (best < 0) { shade_miss<SPEC>(A, pt); return true; }
+    return shade_hit<MOVING, SPEC>(A, pt, best, best_t);
 }
 
 // A path ended: bank its radiance in the sample buffer (the resolve kernel adds the samples of a pixel
@@ -296,7 +304,7 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
     for (; s < n; ++s) test(geom[s], MOVING ? vel[s] : zero, s);
 }
 
-template <bool MOVING>
+template <bool MOVING, int SPEC>
 __global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
@@ -307,16 +315,16 @@ __global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
     for (;;) {
         if (fetch_pixel(A, !have && !dead, px, dead, rs)) { have = true; newpath = true; }
         if (__ballot(!dead) == 0ull) break;
-        if (have && newpath) { newpath = false; start_path(A, px, pt); n_rays++; }
+        if (have && newpath) { newpath = false; start_path<SPEC>(A, px, pt); n_rays++; }
         if (have) {
             bool finished;
-            if (A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
+            if (!SPEC && A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
                 pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0); finished = true;
             } else {
                 int best; float best_t;
                 closest_brute<MOVING>(A.sc, pt.o, pt.d, pt.tm, A.mint, A.maxt, best, best_t);
                 n_seg++;
-                finished = shade<MOVING>(A, pt, best, best_t);
+                finished = shade<MOVING, SPEC>(A, pt, best, best_t);
             }
             if (finished) {
                 if (finish_path(A, px, pt)) have = false;
@@ -526,7 +534,7 @@ __device__ __forceinline__ int trav_node(const DevBvh &bv, Trav &tr, int *stack)
 #ifndef RTW_BVH_WAVES
 #define RTW_BVH_WAVES 4        /* min waves per SIMD the register allocator must leave room for */
 #endif
-template <bool MOVING, bool LDSN>
+template <bool MOVING, bool LDSN, int SPEC>
 __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KArgs A) {
     // per-lane traversal stack, [level][thread]: a level is one conflict-free LDS row.  The LDS-node
     // variant has <= 512 nodes and < 32768 spheres, so its entries fit 16 bits: 16 KB stack + 16 KB nodes.
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                 if (inflight) {
                     inflight = false;
                     n_seg++;
-                    path_done = shade<MOVING>(A, pt, tr.best, tr.best_t);
+                    path_done = shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t);
                 }
                 if (path_done) { path_done = false; if (finish_path(A, px, pt)) have = false; else newpath = true; }
                 need_unit = !have;
@@ -592,9 +600,9 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                 if (exhausted) ph = PH_DEAD;
                 if (have) {
                     // c. next camera ray (a lane whose path continues keeps its scattered ray)
-                    if (newpath) { newpath = false; start_path(A, px, pt); n_rays++; }
+                    if (newpath) { newpath = false; start_path<SPEC>(A, px, pt); n_rays++; }
                     // d. start the next closest-hit query
-                    if (A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
+                    if (!SPEC && A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
                         pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
                         path_done = true;                                  // banked on the next SHADE trip
                     } else {
@@ -643,22 +651,29 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
 // host side
 // ================================================================================================
 typedef void (*kernel_fn)(const KArgs);
-static kernel_fn pick_kernel(bool moving, uint32_t accel, bool lds_nodes) {
+static bool is_common_config(const KArgs &a) {
+    return a.integrator == RTW_INTEGRATOR_GRADIENT && a.sampler == RTW_SAMPLER_ROW && a.depth >= 1 && !a.has_textures;
+}
+template <int SPEC>
+static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, bool lds_nodes) {
     if (accel == RTW_ACCEL_BVH) {
-        if (lds_nodes) return moving ? render_bvh<true, true> : render_bvh<false, true>;
-        return moving ? render_bvh<true, false> : render_bvh<false, false>;
+        if (lds_nodes) return moving ? render_bvh<true, true, SPEC> : render_bvh<false, true, SPEC>;
+        return moving ? render_bvh<true, false, SPEC> : render_bvh<false, false, SPEC>;
     }
-    return moving ? render_brute<true> : render_brute<false>;
+    return moving ? render_brute<true, SPEC> : render_brute<false, SPEC>;
+}
+static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes) {
+    return is_common_config(a) ? pick_kernel_spec<1>(moving, accel, lds_nodes) : pick_kernel_spec<0>(moving, accel, lds_nodes);
 }
 
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(pick_kernel(moving, accel, a.bvh.nodes16 != nullptr), dim3(grid), dim3(RTW_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(pick_kernel(a, moving, accel, a.bvh.nodes16 != nullptr), dim3(grid), dim3(RTW_BLOCK), 0, stream, a);
     hipLaunchKernelGGL(resolve_kernel, dim3((a.n_tiles * 64u + RTW_BLOCK - 1) / RTW_BLOCK), dim3(RTW_BLOCK), 0, stream, a);
 }
 
-uint32_t kernel_blocks_per_cu(bool moving, uint32_t accel, bool lds_nodes) {
+uint32_t kernel_blocks_per_cu(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pick_kernel(moving, accel, lds_nodes), RTW_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pick_kernel(a, moving, accel, lds_nodes), RTW_BLOCK, 0) != hipSuccess || n < 1) n = 1;
     return (uint32_t)(n > 8 ? 8 : n);
 }
 

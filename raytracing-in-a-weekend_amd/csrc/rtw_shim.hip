@@ -29,6 +29,7 @@ struct rtw_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scene
     bool has_scene = false;
+    bool has_textures = false;
     DevScene sc{};
     float bg[3] = { 0, 0, 0 };
     void *d_geom = nullptr, *d_vel = nullptr, *d_mat = nullptr, *d_tex = nullptr, *d_texels = nullptr;
@@ -185,6 +186,8 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     c->sc.tex = (const RtwTexture *)c->d_tex; c->sc.texels = (const float *)c->d_texels;
     c->sc.n = s->n_spheres; c->sc.moving = moving ? 1u : 0u;
     std::memcpy(c->bg, s->background, sizeof c->bg);
+    c->has_textures = false;
+    for (uint32_t i = 0; i < s->n_spheres; i++) if (s->spheres[i].tex >= 0) c->has_textures = true;
     c->has_scene = true;
     return RTW_OK;
 }
@@ -210,6 +213,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     a.n_samples = sampler_count(p->sampler, p->samples, &a.s_root);
     if (a.n_samples == 0) return RTW_E_INVALID;
     a.sampler = p->sampler; a.integrator = p->integrator; a.depth = p->depth;
+    a.has_textures = c->has_textures ? 1u : 0u;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
     a.inv_gamma = host_div(1.0f, p->gamma);                       // viewport.rs:232
     a.mint = p->mint; a.maxt = p->maxt;
@@ -260,7 +264,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     }
 
     // persistent grid: as many workgroups as the kernel's registers let be resident, capped by the work
-    uint32_t per_cu = kernel_blocks_per_cu(c->sc.moving != 0, p->accel, c->bvh.nodes16 != nullptr && !(p->flags & RTW_FLAG_GLOBAL_NODES));
+    uint32_t per_cu = kernel_blocks_per_cu(a, c->sc.moving != 0, p->accel, c->bvh.nodes16 != nullptr && !(p->flags & RTW_FLAG_GLOBAL_NODES));
     if (const char *e = getenv("RTW_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = (uint32_t)v; }   // occupancy experiments
 
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream));
