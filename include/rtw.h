@@ -239,6 +239,12 @@ int rtw_write_png_f32(const char *path, const float *rgb, uint32_t width, uint32
 /* write_ppm (C++/src/ppm_writer.cpp:12-27): P3 text with the C++ truncation int(255 c). */
 int rtw_write_ppm_f32(const char *path, const float *rgb, uint32_t width, uint32_t height);
 
+/* Host-side self-check of the acceleration structure rtw_ctx_set_scene would build (no GPU): every sphere is
+ * reachable exactly once (tree leaf or big list), nested bounds, time-expanded for [t_begin, t_end], the f16 copy
+ * contains the f32 boxes, depth within the device stack.  RTW_OK or RTW_E_INVALID; optional outputs describe the tree. */
+int rtw_bvh_validate(const RtwScene *scene, float t_begin, float t_end,
+                     uint32_t *n_nodes, uint32_t *depth, uint32_t *n_big, uint32_t *has_f16);
+
 /* Scene generators for the BASELINE configs.  Each fills caller arrays; call with
  * spheres == NULL to query the counts.  Returns RTW_OK or RTW_E_INVALID if capacity is too small. */
 enum {

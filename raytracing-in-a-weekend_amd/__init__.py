@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
                                       C.POINTER(RtwTexture), C.c_uint32, C.POINTER(C.c_uint32), fp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.rtw_write_png_f32.argtypes = [C.c_char_p, fp, C.c_uint32, C.c_uint32]
     L.rtw_write_ppm_f32.argtypes = [C.c_char_p, fp, C.c_uint32, C.c_uint32]
+    L.rtw_bvh_validate.argtypes = [C.POINTER(RtwScene), C.c_float, C.c_float] + [C.POINTER(C.c_uint32)] * 4
     L.rtw_scene_generate.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(RtwSphere), C.c_uint32, C.POINTER(C.c_uint32),
                                      C.POINTER(RtwTexture), C.c_uint32, C.POINTER(C.c_uint32),
                                      fp, C.c_uint32, C.POINTER(C.c_uint32)]

@@ -513,3 +513,60 @@ void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end,
 }
 
 } // namespace rtw
+
+// Host-side self-check of the acceleration structure (no GPU): every tree sphere is reachable exactly once,
+// its time-expanded bounds lie inside the box its parent stores for it and inside every ancestor's, the f16
+// copy (when present) contains the f32 boxes, depth <= RTW_BVH_STACK, big + tree spheres == all spheres.
+extern "C" int rtw_bvh_validate(const RtwScene *sc, float t_begin, float t_end, uint32_t *n_nodes, uint32_t *depth, uint32_t *n_big, uint32_t *has_f16) {
+    using namespace rtw;
+    if (!sc || (sc->n_spheres && !sc->spheres)) return RTW_E_INVALID;
+    BvhBuild b;
+    build_bvh(sc->spheres, sc->n_spheres, t_begin, t_end, b);
+    if (n_nodes) *n_nodes = (uint32_t)b.nodes.size();
+    if (depth) *depth = b.depth;
+    if (n_big) *n_big = (uint32_t)b.big.size();
+    if (has_f16) *has_f16 = b.nodes16.empty() ? 0u : 1u;
+    std::vector<int> seen(sc->n_spheres, 0);
+    for (uint32_t i : b.big) { if (i >= sc->n_spheres || seen[i]++) return RTW_E_INVALID; }
+    if (b.depth > RTW_BVH_STACK) return RTW_E_INVALID;
+    auto half = [](uint16_t x) { _Float16 v; std::memcpy(&v, &x, 2); return (float)v; };
+    struct Item { int32_t ref; float lo[3], hi[3]; uint32_t d; };
+    std::vector<Item> todo;
+    if (b.root != std::numeric_limits<int32_t>::min()) {
+        Item r; r.ref = b.root; r.d = 0;
+        for (int k = 0; k < 3; k++) { r.lo[k] = -FLT_MAX; r.hi[k] = FLT_MAX; }
+        todo.push_back(r);
+    }
+    while (!todo.empty()) {
+        Item it = todo.back(); todo.pop_back();
+        if (it.d > RTW_BVH_STACK) return RTW_E_INVALID;
+        if (it.ref < 0) {
+            const uint32_t s = (uint32_t)~it.ref;
+            if (s >= sc->n_spheres || seen[s]++) return RTW_E_INVALID;
+            const RtwSphere &sp = sc->spheres[s];
+            for (int k = 0; k < 3; k++) for (float t : { t_begin, t_end }) {
+                const float c = sp.center[k] + sp.velocity[k] * t, r = std::fabs(sp.radius);
+                if (!(c - r >= it.lo[k] && c + r <= it.hi[k])) return RTW_E_INVALID;
+            }
+            continue;
+        }
+        if ((size_t)it.ref >= b.nodes.size()) return RTW_E_INVALID;
+        const BvhNode &n = b.nodes[it.ref];
+        for (int c = 0; c < 2; c++) {
+            Item ch; ch.ref = c ? n.c1 : n.c0; ch.d = it.d + 1;
+            for (int k = 0; k < 3; k++) {
+                ch.lo[k] = c ? n.lo1[k] : n.lo0[k]; ch.hi[k] = c ? n.hi1[k] : n.hi0[k];
+                if (!(ch.lo[k] >= it.lo[k] && ch.hi[k] <= it.hi[k] && ch.lo[k] <= ch.hi[k])) return RTW_E_INVALID;
+                if (!b.nodes16.empty()) {
+                    const BvhNode16 &h = b.nodes16[it.ref];
+                    const float l16 = half(c ? h.lo1[k] : h.lo0[k]), h16 = half(c ? h.hi1[k] : h.hi0[k]);
+                    if (!(l16 <= ch.lo[k] && h16 >= ch.hi[k])) return RTW_E_INVALID;
+                    if ((int32_t)(c ? h.c1 : h.c0) != ch.ref) return RTW_E_INVALID;
+                }
+            }
+            todo.push_back(ch);
+        }
+    }
+    for (uint32_t i = 0; i < sc->n_spheres; i++) if (seen[i] != 1) return RTW_E_INVALID;
+    return RTW_OK;
+}

@@ -205,3 +205,41 @@ def test_missing_hip_library_fails_loudly():
             "try:\n    R.lib(); print('LOADED')\nexcept ImportError as e:\n    print('IMPORTERROR', 'no CPU fallback' in str(e))\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert "IMPORTERROR True" in out.stdout, out.stdout + out.stderr
+
+
+def _validate(scene, t0=0.0, t1=0.0):
+    n, d, b, h = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = R.lib().rtw_bvh_validate(C.byref(scene.pod), t0, t1, C.byref(n), C.byref(d), C.byref(b), C.byref(h))
+    return rc, n.value, d.value, b.value, h.value
+
+
+def test_bvh_builder_invariants():
+    """The host BVH (csrc/rtw_host.cpp build_bvh): every sphere exactly once, nested time-expanded bounds, f16 copy
+    contains the f32 boxes, depth within the device stack -- for the config scenes and for adversarial ones."""
+    rc, n, d, b, h = _validate(R.Scene.generate(R.SCENE_C2))
+    assert (rc, n, b, h) == (0, 483, 1, 1) and d <= 32            # ground kept outside the tree, 484 leaves
+    rc, n, d, b, h = _validate(R.Scene.generate(R.SCENE_C5), 0.0, 1 / 30)
+    assert (rc, b, h) == (0, 1, 1)
+    rc, n, d, b, h = _validate(R.Scene.generate(R.SCENE_C4))
+    assert (rc, n, b) == (0, 181, 1)
+    rng = np.random.default_rng(11)
+    # many coincident centres, a line of spheres, wildly different radii, big coordinates (no f16 copy), > 512 nodes
+    cases = {
+        "coincident": [R.Sphere.new((0, 0, 0), 0.1 + 0.001 * i) for i in range(70)],
+        "line": [R.Sphere.new((i * 0.5, 0, 0), 0.3) for i in range(200)],
+        "radii": [R.Sphere.new(rng.uniform(-5, 5, 3), float(10 ** rng.uniform(-3, 2))) for _ in range(120)],
+        "far": [R.Sphere.new(rng.uniform(-1, 1, 3) + 5e4, 0.5) for _ in range(40)],
+        "many": [R.Sphere.new(rng.uniform(-30, 30, 3), 0.4) for _ in range(900)],
+        "moving": [R.Sphere.new_moving(rng.uniform(-5, 5, 3), 0.4, None, None, rng.uniform(-20, 20, 3)) for _ in range(100)],
+        "one": [R.Sphere.new((0, 0, -1), 0.5)], "two": [R.Sphere.new((0, 0, -1), 0.5), R.Sphere.new((1, 0, -1), 0.5)], "none": [],
+    }
+    for name, spheres in cases.items():
+        t1 = 0.5 if name == "moving" else 0.0
+        rc, n, d, b, h = _validate(R.Scene(spheres), 0.0, t1)
+        assert rc == 0 and d <= 32, name
+        if name == "far":
+            assert h == 0                       # coordinates beyond the f16 guard: global f32 nodes only
+        if name == "many":
+            assert h == 0 and n + b + 1 == 900  # more than 512 nodes: no LDS copy
+        if name in ("one", "none"):
+            assert n == 0
