@@ -499,7 +499,7 @@ void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end,
 
     // f16 copy for the LDS-resident traversal: only when it fits and every coordinate is far inside the
     // f16 range (outward rounding then costs <= 2^-11 relative per plane)
-    if (!out.nodes.empty() && out.nodes.size() <= RTW_LDS_NODES_MAX && n < 32768u && out.abs_max < 30000.0f) {
+    if (!out.nodes.empty() && out.nodes.size() <= RTW_LDS_NODES_MAX && n <= RTW_LDS_GEOM_MAX && out.abs_max < 30000.0f) {
         out.nodes16.resize(out.nodes.size());
         for (size_t i = 0; i < out.nodes.size(); i++) {
             const BvhNode &a = out.nodes[i]; BvhNode16 &b = out.nodes16[i];

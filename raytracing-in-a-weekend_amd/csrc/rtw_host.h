@@ -35,9 +35,10 @@ struct BvhNode16 {
 };
 static_assert(sizeof(BvhNode16) == 32, "BvhNode16 must be 32 bytes");
 #define RTW_LDS_NODES_MAX 512 // inner nodes the LDS variant holds (16 KB)
+#define RTW_LDS_GEOM_MAX 640  // spheres whose {centre, r^2} the LDS variant also keeps on chip for the leaf tests (10 KB)
 
 #define RTW_MAX_BIG 16        // spheres far larger than the rest are tested exactly, outside the tree
-#define RTW_BVH_STACK 32      // builder guarantees depth <= RTW_BVH_STACK
+#define RTW_BVH_STACK 24      // builder guarantees depth <= RTW_BVH_STACK (median-split fallback near the limit)
 
 struct BvhBuild {
     std::vector<BvhNode> nodes;          // nodes[0] is the root (absent when < 2 tree spheres)

@@ -16,6 +16,7 @@ struct DevBvh {
     const f4 *big_vel;
     const uint32_t *big_index;    // their indices in the scene list
     uint32_t n_big;
+    uint32_t depth;               // tree depth (the stack needs depth + 1 levels)
     int32_t root;                 // node index; ~sphere when the tree is a single leaf; INT32_MIN when empty
     float cx, cy, cz;             // centre C of the tree spheres' centres
     float centre_radius;          // R_c
@@ -40,6 +41,8 @@ struct KArgs {
     uint32_t s_root;              // strata per axis (STRATIFIED / CENTRES)
     uint32_t sampler, integrator, depth;
     uint32_t has_textures;        // any sphere with an image texture (selects the generic kernel)
+    uint32_t lds_bytes;           // dynamic LDS of the BVH kernel: stack | f16 nodes | sphere geometry
+    uint32_t lds_nodes_off, lds_geom_off;   // byte offsets (16-aligned); geom_off == 0: geometry stays in global memory
     uint32_t seed_lo, seed_hi;
     float inv_gamma, mint, maxt;
     float bg[3];

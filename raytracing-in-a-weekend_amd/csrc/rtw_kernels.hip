@@ -536,15 +536,21 @@ __device__ __forceinline__ int trav_node(const DevBvh &bv, Trav &tr, int *stack)
 #endif
 template <bool MOVING, bool LDSN, int SPEC>
 __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KArgs A) {
-    // per-lane traversal stack, [level][thread]: a level is one conflict-free LDS row.  The LDS-node
-    // variant has <= 512 nodes and < 32768 spheres, so its entries fit 16 bits: 16 KB stack + 16 KB nodes.
+    // LDS is all dynamic, sized by the host for THIS tree (rtw_ctx_render): the per-lane traversal stack
+    // [level][thread] (a level is one conflict-free row; depth + 1 levels, 16-bit entries in the LDS-node
+    // variant), then -- LDS-node variant -- the f16 nodes and, when it does not cost a resident workgroup,
+    // {centre, r^2} of every sphere for the leaf tests.  Book-1: 6 KB + 15.5 KB (+ 7.8 KB).
     typedef typename std::conditional<LDSN, short, int>::type stack_t;
-    __shared__ stack_t stack[RTW_BVH_STACK * RTW_BLOCK];
-    __shared__ u4 lnodes[LDSN ? RTW_LDS_NODES_MAX * 2 : 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    stack_t *stack = (stack_t *)lds_raw;
+    u4 *lnodes = (u4 *)(lds_raw + A.lds_nodes_off);
+    f4 *lgeom = (f4 *)(lds_raw + A.lds_geom_off);
+    const bool geom_in_lds = LDSN && A.lds_geom_off != 0u;
     const DevScene &sc = A.sc;
     if (LDSN) {
         const u4 *src = (const u4 *)A.bvh.nodes16;
         for (uint32_t i = threadIdx.x; i < A.bvh.n_nodes * 2u; i += RTW_BLOCK) lnodes[i] = src[i];
+        if (geom_in_lds) for (uint32_t i = threadIdx.x; i < sc.n; i += RTW_BLOCK) lgeom[i] = sc.geom[i];
         __syncthreads();
     }
 
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
             uint32_t live = nT;
             for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
                 c_steps[0]++; c_lanes[0] += live;
-                if (ph == PH_TRAV) { n_nodes++; ph = LDSN ? trav_node_lds(lnodes, tr, (short *)stack) : trav_node(A.bvh, tr, (int *)stack); }
+                if (ph == PH_TRAV) { n_nodes++; ph = LDSN ? trav_node_lds((const u4 *)lnodes, tr, (short *)stack) : trav_node(A.bvh, tr, (int *)stack); }
                 if (u + 1 >= RTW_TRAV_UNROLL) break;
                 live = (uint32_t)__popcll(__ballot(ph == PH_TRAV));
                 if (live == 0u) break;
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
             c_steps[1]++; c_lanes[1] += nL;
             if (ph == PH_LEAF) {
                 const uint32_t s = (uint32_t)~tr.node;
-                exact_sphere<MOVING>(sc.geom[s], MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
+                exact_sphere<MOVING>(geom_in_lds ? lgeom[s] : sc.geom[s], MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
                 n_tests++;
                 tr.hi_lim = tr.best_t + tr.tau_t;
                 ph = trav_pop(tr, stack);
@@ -667,13 +673,13 @@ static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool l
 }
 
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(pick_kernel(a, moving, accel, a.bvh.nodes16 != nullptr), dim3(grid), dim3(RTW_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(pick_kernel(a, moving, accel, a.bvh.nodes16 != nullptr), dim3(grid), dim3(RTW_BLOCK), a.lds_bytes, stream, a);
     hipLaunchKernelGGL(resolve_kernel, dim3((a.n_tiles * 64u + RTW_BLOCK - 1) / RTW_BLOCK), dim3(RTW_BLOCK), 0, stream, a);
 }
 
 uint32_t kernel_blocks_per_cu(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pick_kernel(a, moving, accel, lds_nodes), RTW_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pick_kernel(a, moving, accel, lds_nodes), RTW_BLOCK, a.lds_bytes) != hipSuccess || n < 1) n = 1;
     return (uint32_t)(n > 8 ? 8 : n);
 }
 

@@ -175,7 +175,7 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     c->bvh.nodes = (const BvhNode *)c->d_nodes;
     c->bvh.big_geom = (const f4 *)c->d_big_geom; c->bvh.big_vel = (const f4 *)c->d_big_vel;
     c->bvh.big_index = (const uint32_t *)c->d_big_index; c->bvh.n_big = (uint32_t)bb.big.size();
-    c->bvh.root = bb.root;
+    c->bvh.root = bb.root; c->bvh.depth = bb.depth;
     c->bvh.cx = bb.centre[0]; c->bvh.cy = bb.centre[1]; c->bvh.cz = bb.centre[2];
     c->bvh.centre_radius = bb.centre_radius;
     c->bvh.r_max2 = bb.r_max * bb.r_max * 1.000001f;
@@ -261,6 +261,23 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
             c->d_out_cap = out_bytes;
         }
         a.out = c->d_out;
+    }
+
+    // dynamic LDS layout of the BVH kernel for this tree
+    if (p->accel == RTW_ACCEL_BVH) {
+        const bool ldsn = a.bvh.nodes16 != nullptr;
+        uint32_t levels = c->bvh.depth + 1; if (levels < 4) levels = 4; if (levels > RTW_BVH_STACK) levels = RTW_BVH_STACK;
+        uint32_t off = levels * RTW_BLOCK * (ldsn ? 2u : 4u);
+        off = (off + 15u) & ~15u;
+        if (ldsn) {
+            a.lds_nodes_off = off; off += c->bvh.n_nodes * 32u; off = (off + 15u) & ~15u;
+            // sphere geometry rides along only while the workgroup stays under 1/6 of the CU's 160 KiB, i.e. while
+            // it does not cost a resident workgroup at the kernel's register budget (6 waves/SIMD)
+            bool geom = off + c->sc.n * 16u <= 160u * 1024u / 6u;
+            if (const char *e = getenv("RTW_LDS_GEOM")) geom = atoi(e) != 0 && c->sc.n <= RTW_LDS_GEOM_MAX;
+            if (geom) { a.lds_geom_off = off; off += c->sc.n * 16u; }
+        }
+        a.lds_bytes = off;
     }
 
     // persistent grid: as many workgroups as the kernel's registers let be resident, capped by the work
