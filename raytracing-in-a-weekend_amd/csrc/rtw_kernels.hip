@@ -31,9 +31,10 @@ namespace rtw {
 // shared pieces
 // ================================================================================================
 
-// SPEC == 1 is the specialisation for the common configuration -- ray_color_gradient, render_row sampler, depth >= 1,
-// no image textures (every BASELINE config but C5's textured ground): the integrator/sampler switches fold
-// away at compile time.  SPEC == 0 reads them from the (wave-uniform) kernel arguments.
+// SPEC != 0 is the specialisation for the common configuration -- ray_color_gradient, render_row sampler, depth >= 1
+// (every BASELINE config): the integrator/sampler switches fold away at compile time.  SPEC == 1 additionally knows
+// that no sphere carries an image texture (no atan2f/acosf code at all); SPEC == 2 keeps the texture lookup (C5).
+// SPEC == 0 reads everything from the (wave-uniform) kernel arguments.
 template <int SPEC> __device__ __forceinline__ uint32_t integ(const KArgs &A) { return SPEC ? (uint32_t)RTW_INTEGRATOR_GRADIENT : A.integrator; }
 template <int SPEC> __device__ __forceinline__ uint32_t samp(const KArgs &A) { return SPEC ? (uint32_t)RTW_SAMPLER_ROW : A.sampler; }
 
@@ -166,7 +167,7 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, fl
         pt.L = mk(1.0f, 1.0f, 0.0f) * pt.thr;                // glass_tests.rs:35-37
         return true;
     }
-    const v3 cm = SPEC ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
+    const v3 cm = SPEC == 1 ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
     if (integ<SPEC>(A) == RTW_INTEGRATOR_RUST2) {              // Rust2/src/viewport/ray_color.rs:17-31, front-to-back
         const v3 nd2 = on_hit_rust2(mat, normal, pt.d, pt.rng);
         pt.L = pt.L + ld3(mat.emitted) * pt.thr;
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
 // ================================================================================================
 typedef void (*kernel_fn)(const KArgs);
 static bool is_common_config(const KArgs &a) {
-    return a.integrator == RTW_INTEGRATOR_GRADIENT && a.sampler == RTW_SAMPLER_ROW && a.depth >= 1 && !a.has_textures;
+    return a.integrator == RTW_INTEGRATOR_GRADIENT && a.sampler == RTW_SAMPLER_ROW && a.depth >= 1;
 }
 template <int SPEC>
 static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, bool lds_nodes) {
@@ -669,7 +670,8 @@ static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, bool lds_nodes) {
     return moving ? render_brute<true, SPEC> : render_brute<false, SPEC>;
 }
 static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes) {
-    return is_common_config(a) ? pick_kernel_spec<1>(moving, accel, lds_nodes) : pick_kernel_spec<0>(moving, accel, lds_nodes);
+    if (!is_common_config(a)) return pick_kernel_spec<0>(moving, accel, lds_nodes);
+    return a.has_textures ? pick_kernel_spec<2>(moving, accel, lds_nodes) : pick_kernel_spec<1>(moving, accel, lds_nodes);
 }
 
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream) {
