@@ -5,23 +5,24 @@
 // integrator (Rust/src/viewport/ray_color.rs:12-92, written front-to-back instead of recursively)
 // and the closest-hit + scatter (objects/sphere.rs:99-147, objects/materials.rs:105-154).
 //
-// Execution shape common to both kernels (wave64, CDNA4):
-//   * persistent workgroups (4 waves); a lane owns ONE pixel at a time and walks its samples in
-//     order, so the per-pixel f32 sum has the reference's order (viewport.rs:299 `color +=`);
-//   * a lane whose path ends starts its pixel's next sample at once ("regeneration"), and a lane
-//     whose pixel is finished pulls the next pixel index from a global queue with ONE
-//     wave-aggregated atomic (ballot + mbcnt);
-//   * work items are ordered 8x8-tile-major so the 64 pixels a wave pulls together are one tile.
+// Execution shape common to both render kernels (wave64, CDNA4):
+//   * persistent workgroups (4 waves); the work unit is (8x8 tile, chunk of 4 consecutive samples, pixel of
+//     the tile); a wave takes 64 units -- one tile x chunk -- from the global queue with ONE atomic into a
+//     wave-local reserve and hands them to its lanes as they run dry (ballot + mbcnt);
+//   * a lane whose path ends starts the next sample of its unit at once ("regeneration");
+//   * every finished path banks its radiance (12 B) in HBM; resolve_kernel then adds a pixel's samples IN
+//     SAMPLE ORDER, so the per-pixel f32 sum has the reference's order (viewport.rs:299 `color +=`) although
+//     a pixel's samples were traced by many lanes.
 //
 // render_brute: every lane tests every sphere in list order; {centre, r^2} arrive by wave-uniform
 //   SCALAR loads, so the VALU ops take their sphere operands straight from SGPRs.
 // render_bvh:   per-lane BVH traversal.  Lanes of a wave diverge (different node counts, leaves at
 //   different moments, paths ending at different moments), so the wave runs a tiny scheduler: every
-//   lane is in one of three phases -- TRAVERSE (one inner-node visit = two slab tests), LEAF (one exact
-//   sphere test), SHADE (finish a segment: scatter / sky, next sample, next pixel, set up the next
-//   traversal) -- and each loop trip executes the ONE phase most lanes are waiting for
-//   (ballot + popcount), the other lanes keep their state (traversal stack in LDS) and wait.  That
-//   turns three nested divergent loops into one loop whose body runs with most lanes live.
+//   lane is in one of three phases -- TRAVERSE (inner-node visits = two slab tests each), LEAF (one exact
+//   sphere test), SHADE (finish a segment: scatter / sky, next sample, next unit, set up the next
+//   traversal) -- and each loop trip executes ONE phase (ballot + popcount), the other lanes keep their
+//   state (traversal stack in LDS) and wait.  That turns three nested divergent loops into one loop whose
+//   body runs with most lanes live.
 #include "rtw_kernels.h"
 #include <type_traits>
 
