@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTW_ABI_VERSION 1
+#define RTW_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------- */
 #define RTW_OK              0
@@ -113,7 +113,41 @@ typedef struct RtwTexture {
     uint32_t reserved;
 } RtwTexture;
 
-/* `Scene` restricted to spheres (Rust/src/viewport.rs:79-151). */
+/* `Quad` (Rust/src/objects/quad.rs:8-20) with its `Material` inlined.  The derived fields of Quad::new
+ * (normal = unit(u x v), d = normal . origin, w = n / n.n; quad.rs:96-108) are recomputed by the library.
+ * A quad has no col_mod: the hit's albedo is the texel alone (quad.rs:64-79) -- tex < 0 means the 1x1
+ * ImageTexture::from_color(tex_color), else texel (floor(alfa*row), floor(beta*col)) of textures[tex].
+ * `velocity` is carried by the reference's struct but not used by its hit test (quad.rs:37-81). */
+typedef struct RtwQuad {
+    float origin[3];
+    float u[3];
+    float v[3];
+    float velocity[3];
+    float tex_color[3];
+    float metallicness;
+    float opacity;
+    float ir;
+    float emitted[3];
+    int32_t tex;
+} RtwQuad;
+
+/* `Instance` (Rust/src/objects/instance.rs:27-38): a group of spheres and quads with a translation and an
+ * Euler rotation (Vec3::rotated, vec3.rs:161-181 -- restated as written, including its non-orthogonal
+ * terms for rotations about more than one axis), hit in local coordinates (instance.rs:250-310).
+ * medium != 0 selects `dist_fn = const_density` (instance.rs:24-26): the hit becomes a scattering event
+ * at distance ln(xi) / -density behind the surface with a random normal (constant-density smoke). */
+enum { RTW_MEDIUM_SURFACE = 0, RTW_MEDIUM_CONST_DENSITY = 1 };
+typedef struct RtwInstance {
+    uint32_t first_sphere, n_spheres;   /* members: RtwScene.inst_spheres[first_sphere .. +n_spheres) */
+    uint32_t first_quad, n_quads;       /*          RtwScene.inst_quads[first_quad .. +n_quads)       */
+    float translation[3];
+    float rotation[3];
+    float density;
+    uint32_t medium;                    /* RTW_MEDIUM_* */
+} RtwInstance;
+
+/* `Scene` (Rust/src/viewport.rs:79-151): spheres, quads, instances, background colour.  Sphere-only callers
+ * (Scene::new_sphere) leave everything after `background` zero. */
 typedef struct RtwScene {
     const RtwSphere  *spheres;
     const RtwTexture *textures;   /* may be NULL when n_textures == 0 */
@@ -121,7 +155,15 @@ typedef struct RtwScene {
     uint32_t n_spheres;
     uint32_t n_textures;
     uint32_t n_texels;
-    float    background[3];       /* Scene.background_color (BG_COLOR integrator only) */
+    float    background[3];       /* Scene.background_color (BG_COLOR / RUST2 integrators) */
+    const RtwQuad     *quads;         /* Scene.quads                                       */
+    const RtwInstance *instances;     /* Scene.instances                                   */
+    const RtwSphere   *inst_spheres;  /* member pools of the instances                     */
+    const RtwQuad     *inst_quads;
+    uint32_t n_quads;
+    uint32_t n_instances;
+    uint32_t n_inst_spheres;
+    uint32_t n_inst_quads;
 } RtwScene;
 
 typedef struct RtwParams {
@@ -165,6 +207,7 @@ typedef struct RtwStats {
      * and the lanes that were live in them; lanes / (64 * steps) is the SIMD efficiency of a phase. */
     uint64_t phase_steps[3];
     uint64_t phase_lanes[3];
+    uint64_t quad_tests;     /* ray/quad plane tests (top-level quads and instance members) */
 } RtwStats;
 
 typedef struct rtw_ctx rtw_ctx;
@@ -216,6 +259,12 @@ int rtw_sphere_new(const float origin[3], float radius, const float *col_mod,
 /* Sphere::new_with_texture (sphere.rs:200-224). */
 int rtw_sphere_new_with_texture(const float origin[3], float radius, const float *col_mod,
                                 const float *mat3, const float *velocity, int32_t tex, RtwSphere *out);
+/* Quad::new (quad.rs:84-110) with ImageTexture::from_color(color): velocity == NULL -> 0, emitted == NULL -> 0. */
+int rtw_quad_new(const float origin[3], const float u[3], const float v[3], const float *mat3,
+                 const float *emitted, const float color[3], RtwQuad *out);
+/* Instance::new_box(a, b, tex, mat) (instance.rs:83-176): the six quads of the axis-aligned box, in the
+ * reference's order, written to quads6[0..6). */
+int rtw_box_quads(const float a[3], const float b[3], const float *mat3, const float color[3], RtwQuad quads6[6]);
 /* Rows a partition owns (see RtwParams). */
 uint32_t rtw_part_rows(uint32_t height, uint32_t row_block, uint32_t part_index, uint32_t part_count);
 /* write_img_f32 quantisation: round(clamp(c*255, 0, 255)) (Rust/src/write_img.rs:11-15). */
@@ -252,12 +301,22 @@ enum {
     RTW_SCENE_C2_BOOK1_FINAL   = 2, /* Book-1 final random spheres, ~485                          */
     RTW_SCENE_C4_DIELECTRIC    = 4, /* 9x9 hollow-glass grid + fuzzy metal                         */
     RTW_SCENE_C5_MOTION_CHECKER= 5, /* C2 with moving lambert spheres + 4x2 image-textured ground  */
-    RTW_SCENE_METAL_TEST       = 6  /* 4-sphere metal_test (material_tests.rs:105-167)             */
+    RTW_SCENE_METAL_TEST       = 6, /* 4-sphere metal_test (material_tests.rs:105-167)             */
+    RTW_SCENE_QUAD_TEST        = 7, /* the five quads of quad_test (objects/quad.rs:152-299)       */
+    RTW_SCENE_PRESENTATION     = 8, /* presentation_image (main.rs:89-419): sphere + 6 quads (one a light) +
+                                       a rotated smoke box + a rotated glass pane, black background  */
+    RTW_SCENE_FIRST_FRAME      = 9  /* main()'s seven spheres (main.rs:427-496), the scene of Rust/First frame.png */
 };
 int rtw_scene_generate(uint32_t which, uint64_t scene_seed,
                        RtwSphere *spheres, uint32_t sphere_cap, uint32_t *n_spheres,
                        RtwTexture *textures, uint32_t texture_cap, uint32_t *n_textures,
                        float *texels, uint32_t texel_cap, uint32_t *n_texels);
+/* Same for scenes with quads / instances (7, 8; the sphere-only ids work too).  Any output array may be NULL
+ * when only the counts are wanted: counts[0..5) = spheres, quads, instances, inst_spheres, inst_quads
+ * (these scenes carry no image textures). */
+int rtw_scene_generate_geom(uint32_t which, uint64_t scene_seed, RtwSphere *spheres, RtwQuad *quads,
+                            RtwInstance *instances, RtwSphere *inst_spheres, RtwQuad *inst_quads,
+                            const uint32_t caps[5], uint32_t counts[5], float background[3]);
 /* The camera + params each config is quoted with (width/height/samples/depth/lens/vfov/shutter). */
 int rtw_scene_default_view(uint32_t which, RtwCamera *cam, RtwParams *params);
 

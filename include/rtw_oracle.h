@@ -32,7 +32,7 @@ int rtw_oracle_viewport_new(uint32_t width, float aspect_ratio, const float *vfo
  * (Rust/cerr trace). */
 typedef struct RtwOracleBounce {
     int32_t hit;             /* 1 hit, 0 miss (sky) */
-    int32_t sphere;          /* index of the sphere hit */
+    int32_t sphere;          /* index of the top-level object hit: spheres, then quads, then instances */
     int32_t front_face;      /* !(dir . normal > 0)  */
     int32_t cannot_refract;  /* dielectric only      */
     float   t;
@@ -53,6 +53,10 @@ int rtw_oracle_trace_ray(const float origin[3], const float dir[3], float time,
 /* The RNG, exposed so tests can pin it with known-answer vectors. */
 void  rtw_oracle_rng_seed(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t state[2] /* state, inc */);
 float rtw_oracle_rng_next(uint32_t state[2]);
+/* The natural logarithm the constant-density medium uses (instance.rs:24-26 `gen::<f32>().ln()`): f64 series,
+ * rounded once; bulk form for the exhaustive check over every xi = k * 2^-24. */
+float rtw_oracle_ln(float x);
+void  rtw_oracle_ln_bulk(const float *x, float *out, size_t n);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,10 @@
  *   Rust/src/objects/materials.rs:89-154,213-228 Material::on_hit  -> on_hit()
  *   Rust/src/vec3.rs:188-261              Vec3 math + samplers     -> v3_*, random_*()
  *   Rust/src/texture.rs:259-267           ImageTexture::color_at   -> texel()
+ *   Rust/src/objects/quad.rs:37-110       Quad::collision_normal, Quad::new   -> quad_prepare(), quad_hit()
+ *   Rust/src/objects/instance.rs:250-310  Instance::collision_normal (+ const_density :24-26) -> instance_hit()
+ *   Rust/src/vec3.rs:161-181              Vec3::rotated                       -> rot_make(), v3_rotated()
+ *   Rust/src/viewport.rs:136-150          Scene::collision_normal             -> closest_hit()
  *
  * Parity status.  The reference draws every random number from rand 0.8.5's ThreadRng (OS-seeded
  * ChaCha12, crate NOT vendored under /root/reference, Rust/Cargo.lock) and no reference test pins a
@@ -136,14 +140,18 @@ static inline v3 random_in_unit_disk(rng_t *r) {
 typedef struct { v3 origin, dir; float time; } ray_t;
 static inline v3 ray_at(ray_t r, float t) { return v3_add(r.origin, v3_scale(r.dir, t)); } /* vec3.rs:289 */
 
+/* `Material` (materials.rs:15-20) */
+typedef struct { float metallicness, opacity, ir; float emitted[3]; } mat_t;
+
 typedef struct {
     float t;
     v3 normal, point, col_mod;
-    int sphere;
+    mat_t mat;
+    int sphere;     /* index of the top-level object that was hit: spheres, then quads, then instances */
 } hit_t;
 
 typedef struct {
-    uint64_t segments, sphere_tests;
+    uint64_t segments, sphere_tests, quad_tests;
 } counters_t;
 
 /* Rust `f as usize`: saturating, NaN -> 0 */
@@ -190,15 +198,22 @@ static inline int sphere_hit_t(const RtwSphere *s, ray_t r, float mint, float ma
     return 1;
 }
 
-/* Closest hit in list order: `min_hit == None || min_hit > i` (camera_tests.rs:19-33,
- * aabb/aabb.rs:140-152) -- strict, so the first of equal t wins; a NaN t can only enter first. */
-static int closest_hit(const RtwScene *sc, ray_t r, float mint, float maxt, hit_t *h, counters_t *cn) {
+static inline mat_t sphere_mat(const RtwSphere *s) {
+    mat_t m = { s->metallicness, s->opacity, s->ir, { s->emitted[0], s->emitted[1], s->emitted[2] } };
+    return m;
+}
+
+/* Closest sphere of a list, in list order: `min_hit == None || min_hit > i` (camera_tests.rs:19-33,
+ * aabb/aabb.rs:140-152) -- strict, so the first of equal t wins; a NaN t can only enter first.
+ * (The reference's AABB tree only prunes this loop; its bounds ignore velocity, which this restatement
+ * does not reproduce: DESIGN.md 1.) */
+static int closest_sphere(const RtwScene *sc, const RtwSphere *list, uint32_t n, ray_t r, float mint, float maxt,
+                          hit_t *h, counters_t *cn) {
     int best = -1; float best_t = 0.0f; v3 best_c = { 0, 0, 0 };
-    cn->segments++;
-    for (uint32_t i = 0; i < sc->n_spheres; i++) {
+    for (uint32_t i = 0; i < n; i++) {
         float t; v3 c;
         cn->sphere_tests++;
-        if (!sphere_hit_t(&sc->spheres[i], r, mint, maxt, &t, &c)) continue;
+        if (!sphere_hit_t(&list[i], r, mint, maxt, &t, &c)) continue;
         if (best < 0 || best_t > t) { best = (int)i; best_t = t; best_c = c; }
     }
     if (best < 0) return 0;
@@ -206,8 +221,163 @@ static int closest_hit(const RtwScene *sc, ray_t r, float mint, float maxt, hit_
     h->sphere = best;
     h->point = ray_at(r, best_t);
     h->normal = v3_unit(v3_sub(ray_at(r, best_t), best_c));   /* :127 */
-    h->col_mod = sphere_albedo(sc, &sc->spheres[best], h->normal);
+    h->col_mod = sphere_albedo(sc, &list[best], h->normal);
+    h->mat = sphere_mat(&list[best]);
     return 1;
+}
+
+/* ---- quads (objects/quad.rs) ------------------------------------------------------------------- */
+typedef struct { v3 normal, w; float d; } quad_derived_t;
+
+/* Quad::new (quad.rs:96-108): n = u x v; normal = unit(n); d = normal . origin; w = n / (n . n) */
+static inline quad_derived_t quad_prepare(const RtwQuad *q) {
+    quad_derived_t g;
+    v3 n = v3_cross(v3_ld(q->u), v3_ld(q->v));
+    g.normal = v3_unit(n);
+    g.d = v3_dot(g.normal, v3_ld(q->origin));
+    g.w = v3_div(n, v3_dot(n, n));
+    return g;
+}
+
+/* Quad::collision_normal (quad.rs:37-81) */
+static int quad_hit(const RtwScene *sc, const RtwQuad *q, ray_t r, float mint, float maxt, hit_t *h) {
+    quad_derived_t g = quad_prepare(q);
+    float denominator = v3_dot(g.normal, r.dir);
+    if (fabsf(denominator) <= 1e-8f) return 0;
+    float t = (g.d - v3_dot(g.normal, r.origin)) / denominator;
+    if (t < mint || t > maxt) return 0;
+    v3 point = ray_at(r, t);
+    v3 planar = v3_sub(point, v3_ld(q->origin));
+    float alfa = v3_dot(g.w, v3_cross(planar, v3_ld(q->v)));
+    float beta = v3_dot(g.w, v3_cross(v3_ld(q->u), planar));
+    if (alfa < 0.0f || alfa > 1.0f || beta < 0.0f || beta > 1.0f) return 0;
+    v3 tex;
+    if (q->tex < 0 || (uint32_t)q->tex >= sc->n_textures) {
+        tex = v3_ld(q->tex_color);                 /* 1x1: both indices are 0 */
+    } else {
+        const RtwTexture *tx = &sc->textures[q->tex];
+        uint32_t ix = alfa != 1.0f ? f32_as_usize(floorf(alfa * (float)tx->row)) : tx->row - 1;   /* :66-70 */
+        uint32_t iy = beta != 1.0f ? f32_as_usize(floorf(beta * (float)tx->col)) : tx->col - 1;   /* :71-75 */
+        if (ix > tx->row - 1) ix = tx->row - 1;
+        if (iy > tx->col - 1) iy = tx->col - 1;
+        tex = v3_ld(&sc->texels[3 * (size_t)(tx->texel_offset + iy * tx->row + ix)]);
+    }
+    h->t = t; h->normal = g.normal; h->point = point;
+    h->col_mod = v3_scale(tex, 1.0f);              /* texture.rs:265, noise None */
+    h->mat.metallicness = q->metallicness; h->mat.opacity = q->opacity; h->mat.ir = q->ir;
+    h->mat.emitted[0] = q->emitted[0]; h->mat.emitted[1] = q->emitted[1]; h->mat.emitted[2] = q->emitted[2];
+    return 1;
+}
+
+/* Closest quad of a list in list order (QuadAABB::collision_normal, aabb/qaabb.rs:196-258, prunes this loop). */
+static int closest_quad(const RtwScene *sc, const RtwQuad *list, uint32_t n, ray_t r, float mint, float maxt,
+                        hit_t *h, counters_t *cn) {
+    int best = -1;
+    for (uint32_t i = 0; i < n; i++) {
+        hit_t q;
+        cn->quad_tests++;
+        if (!quad_hit(sc, &list[i], r, mint, maxt, &q)) continue;
+        if (best < 0 || h->t > q.t) { *h = q; h->sphere = (int)i; best = (int)i; }
+    }
+    return best >= 0;
+}
+
+/* ---- instances (objects/instance.rs) ------------------------------------------------------------- */
+/* Vec3::rotated (vec3.rs:161-181), as written: the y-coefficient of x reads `asin*bsin*ccos - asin*ccos`. */
+typedef struct { float asin, acos, bsin, bcos, csin, ccos; } rot_t;
+static inline rot_t rot_make(v3 rot) {
+    rot_t q = { sinf(rot.x), cosf(rot.x), sinf(rot.y), cosf(rot.y), sinf(rot.z), cosf(rot.z) };
+    return q;
+}
+static inline v3 v3_rotated(v3 a, rot_t q) {
+    v3 o;
+    o.x = a.x * q.bcos * q.ccos + a.y * (q.asin * q.bsin * q.ccos - q.asin * q.ccos) + a.z * (q.acos * q.bsin * q.ccos + q.asin * q.csin);
+    o.y = a.x * q.bcos * q.csin + a.y * (q.asin * q.bsin * q.csin + q.acos * q.ccos) + a.z * (q.acos * q.bsin * q.csin - q.asin * q.ccos);
+    o.z = a.x * -q.bsin + a.y * q.asin * q.bcos + a.z * q.acos * q.bcos;
+    return o;
+}
+
+/* ln(x) for a positive normal f32, computed in f64 (atanh series of (m-1)/(m+1), 12 terms) and rounded once:
+ * the correctly rounded result for every xi = k * 2^-24 the RNG can produce (checked exhaustively against logl
+ * in tests/test_oracle_golden.py).  Written out instead of calling libm so that the device, which evaluates
+ * the same f64 operations, returns the same bits.  Rust's f32::ln is the platform logf (<= 1 ulp from this). */
+static inline float ln_f32(float xf) {
+    if (xf == 0.0f) return -INFINITY;
+    uint32_t bits; memcpy(&bits, &xf, 4);
+    int e = (int)(bits >> 23) - 127;
+    uint32_t mb = (bits & 0x007FFFFFu) | 0x3F800000u;
+    float mf; memcpy(&mf, &mb, 4);
+    double m = (double)mf;
+    if (mf > 1.41421354f) { m = m * 0.5; e += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double p = 1.0 / 25.0;
+    p = 1.0 / 23.0 + z * p; p = 1.0 / 21.0 + z * p; p = 1.0 / 19.0 + z * p; p = 1.0 / 17.0 + z * p;
+    p = 1.0 / 15.0 + z * p; p = 1.0 / 13.0 + z * p; p = 1.0 / 11.0 + z * p; p = 1.0 / 9.0 + z * p;
+    p = 1.0 / 7.0 + z * p;  p = 1.0 / 5.0 + z * p;  p = 1.0 / 3.0 + z * p;
+    double lm = 2.0 * s + (2.0 * s) * (z * p);
+    return (float)((double)e * 0.6931471805599453094 + lm);
+}
+float rtw_oracle_ln(float x) { return ln_f32(x); }
+void rtw_oracle_ln_bulk(const float *x, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = ln_f32(x[i]); }
+
+/* closest member of an instance, spheres then quads (instance.rs:263-273: `for i in vec![s_hit, q_hit]`) */
+static int instance_members(const RtwScene *sc, const RtwInstance *in, ray_t r, float mint, float maxt,
+                            hit_t *h, counters_t *cn) {
+    hit_t s_hit, q_hit; int found = 0;
+    if (closest_sphere(sc, sc->inst_spheres + in->first_sphere, in->n_spheres, r, mint, maxt, &s_hit, cn)) { *h = s_hit; found = 1; }
+    if (closest_quad(sc, sc->inst_quads + in->first_quad, in->n_quads, r, mint, maxt, &q_hit, cn)) {
+        if (!found || h->t > q_hit.t) { *h = q_hit; found = 1; }
+    }
+    return found;
+}
+
+/* Instance::collision_normal (instance.rs:250-310) */
+static int instance_hit(const RtwScene *sc, const RtwInstance *in, ray_t r0, float mint, float maxt,
+                        hit_t *h, counters_t *cn, rng_t *rng) {
+    v3 tr = v3_ld(in->translation), rot = v3_ld(in->rotation);
+    rot_t back = rot_make(v3_neg(rot)), fwd = rot_make(rot);
+    ray_t r;                                        /* change to local (:257-258) */
+    r.origin = v3_rotated(v3_sub(r0.origin, tr), back);
+    r.dir = v3_rotated(r0.dir, back);
+    r.time = r0.time;
+    if (!instance_members(sc, in, r, mint, maxt, h, cn)) return 0;
+    if (in->medium == RTW_MEDIUM_CONST_DENSITY) {   /* const_density (:24-26): thread_rng().gen::<f32>().ln() / -d */
+        float distance = ln_f32(rng_f32(rng)) / -in->density;
+        if (distance >= 0.0f) {
+            hit_t second;
+            r.origin = v3_add(h->point, v3_scale(r.dir, distance));
+            if (!instance_members(sc, in, r, mint, maxt, &second, cn)) return 0;   /* left the volume first (:292) */
+            h->point = r.origin;
+            h->normal = random_unit_vec(rng);
+        }
+    }
+    h->point = v3_add(v3_rotated(h->point, fwd), tr);  /* :301-302 */
+    h->normal = v3_rotated(h->normal, fwd);            /* :304 */
+    return 1;
+}
+
+/* Scene::collision_normal (viewport.rs:136-150): spheres, quads, instances; a later hit replaces an earlier
+ * one only when strictly closer.  The three AABB trees (aabb.rs, qaabb.rs, iaabb.rs) only prune the list
+ * walks below; instances are visited in list order (the reference's IAABB order comes from an unseeded
+ * random split axis, aabb/iaabb.rs:87, and matters only for which medium draws first). */
+static int closest_hit(const RtwScene *sc, ray_t r, float mint, float maxt, hit_t *h, counters_t *cn, rng_t *rng) {
+    int found = 0; hit_t c;
+    cn->segments++;
+    if (closest_sphere(sc, sc->spheres, sc->n_spheres, r, mint, maxt, &c, cn)) { *h = c; found = 1; }
+    if (sc->n_quads && closest_quad(sc, sc->quads, sc->n_quads, r, mint, maxt, &c, cn)) {
+        if (!found || h->t > c.t) { *h = c; h->sphere = (int)sc->n_spheres + c.sphere; found = 1; }
+    }
+    if (sc->n_instances) {
+        int ibest = 0; hit_t ih; int ifound = 0;
+        for (uint32_t i = 0; i < sc->n_instances; i++) {
+            if (!instance_hit(sc, &sc->instances[i], r, mint, maxt, &c, cn, rng)) continue;
+            if (!ifound || ih.t > c.t) { ih = c; ibest = (int)i; ifound = 1; }
+        }
+        if (ifound && (!found || h->t > ih.t)) { *h = ih; h->sphere = (int)(sc->n_spheres + sc->n_quads) + ibest; found = 1; }
+    }
+    return found;
 }
 
 /* materials.rs:89-97 */
@@ -231,7 +401,7 @@ static inline float reflectance(float cosine, float ref_idx) {
 typedef struct { ray_t next; v3 emitted; float cos_theta; int front_face, cannot_refract; float ratio; } scatter_t;
 
 /* materials.rs:105-154 (+ diffuse :213-228) */
-static scatter_t on_hit(const RtwSphere *s, const hit_t *h, ray_t r, rng_t *rng, uint32_t flags) {
+static scatter_t on_hit(const mat_t *s, const hit_t *h, ray_t r, rng_t *rng, uint32_t flags) {
     scatter_t o; memset(&o, 0, sizeof o);
     o.emitted = v3_ld(s->emitted);
     o.front_face = !(v3_dot(r.dir, h->normal) > 0.0f);
@@ -302,8 +472,8 @@ static void trace_record(ctx_t *c, int hit, const hit_t *h, const scatter_t *s, 
 static v3 ray_color_gradient_rec(ctx_t *c, ray_t r, uint32_t depth) {
     if (depth < 1) return v3_make(0, 0, 0);
     hit_t h;
-    if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
-        scatter_t s = on_hit(&c->sc->spheres[h.sphere], &h, r, c->rng, c->p->flags);
+    if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn, c->rng)) {
+        scatter_t s = on_hit(&h.mat, &h, r, c->rng, c->p->flags);
         fix_degenerate(&s, &h);
         trace_record(c, 1, &h, &s, r);
         return v3_mul(ray_color_gradient_rec(c, s.next, depth - 1), h.col_mod);
@@ -319,11 +489,11 @@ static v3 ray_color_gradient_iter(ctx_t *c, ray_t r, uint32_t depth) {
     v3 thr = v3_make(1.0f, 1.0f, 1.0f);
     for (uint32_t k = 0; k < depth; k++) {
         hit_t h;
-        if (!closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
+        if (!closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn, c->rng)) {
             trace_record(c, 0, NULL, NULL, r);
             return v3_mul(sky_gradient(r.dir), thr);
         }
-        scatter_t s = on_hit(&c->sc->spheres[h.sphere], &h, r, c->rng, c->p->flags);
+        scatter_t s = on_hit(&h.mat, &h, r, c->rng, c->p->flags);
         fix_degenerate(&s, &h);
         trace_record(c, 1, &h, &s, r);
         thr = v3_mul(thr, h.col_mod);
@@ -341,8 +511,8 @@ static inline float lambertian_scatter_pdf(float cos_theta) {
 static v3 ray_color_bg_rec(ctx_t *c, ray_t r, uint32_t depth) {
     if (depth < 1) return v3_make(0, 0, 0);
     hit_t h;
-    if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
-        const RtwSphere *sp = &c->sc->spheres[h.sphere];
+    if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn, c->rng)) {
+        const mat_t *sp = &h.mat;
         scatter_t s = on_hit(sp, &h, r, c->rng, c->p->flags);
         fix_degenerate(&s, &h);
         trace_record(c, 1, &h, &s, r);
@@ -366,12 +536,12 @@ static v3 ray_color_bg_iter(ctx_t *c, ray_t r, uint32_t depth) {
     int poison = 0;
     for (uint32_t k = 0; k < depth; k++) {
         hit_t h;
-        if (!closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
+        if (!closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn, c->rng)) {
             trace_record(c, 0, NULL, NULL, r);
             L = v3_add(L, v3_mul(v3_ld(c->sc->background), thr));
             goto done;
         }
-        const RtwSphere *sp = &c->sc->spheres[h.sphere];
+        const mat_t *sp = &h.mat;
         scatter_t s = on_hit(sp, &h, r, c->rng, c->p->flags);
         fix_degenerate(&s, &h);
         trace_record(c, 1, &h, &s, r);
@@ -388,7 +558,7 @@ done:
 /* C++/src/tests.cpp:76-97 ray_colorSc: (normal + 1) * 0.5 of the closest hit, else sky */
 static v3 ray_color_normal(ctx_t *c, ray_t r) {
     hit_t h;
-    if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
+    if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn, c->rng)) {
         trace_record(c, 1, &h, NULL, r);
         return v3_scale(v3_make(h.normal.x + 1.0f, h.normal.y + 1.0f, h.normal.z + 1.0f), 0.5f);
     }
@@ -401,11 +571,11 @@ static v3 ray_color_flag(ctx_t *c, ray_t r, uint32_t depth) {
     v3 thr = v3_make(1.0f, 1.0f, 1.0f);
     for (uint32_t k = 0; k < depth; k++) {
         hit_t h;
-        if (!closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
+        if (!closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn, c->rng)) {
             trace_record(c, 0, NULL, NULL, r);
             return v3_mul(v3_make(0.0f, 0.0f, 1.0f), thr);
         }
-        const RtwSphere *sp = &c->sc->spheres[h.sphere];
+        const mat_t *sp = &h.mat;
         if (sp->metallicness != 1.0f) {
             trace_record(c, 1, &h, NULL, r);
             return v3_mul(v3_make(1.0f, 1.0f, 0.0f), thr);
@@ -422,7 +592,7 @@ static v3 ray_color_flag(ctx_t *c, ray_t r, uint32_t depth) {
 /* ---- Rust2 trait surface ------------------------------------------------------ */
 /* Material::on_hit of Rust2/src/objects/material.rs: Lambertian :25-36, Mirror :75-83, MirrorGlass :130-162.
  * The hit's ray is the incoming ray (Hit.r), its normal the outward one (Rust2/src/objects/sphere.rs:56-84). */
-static ray_t rust2_on_hit(const RtwSphere *s, const hit_t *h, ray_t r, rng_t *rng, uint32_t flags) {
+static ray_t rust2_on_hit(const mat_t *s, const hit_t *h, ray_t r, rng_t *rng, uint32_t flags) {
     ray_t o; o.origin = h->point; o.time = r.time;
     if (s->opacity > 0.0f) {                                      /* MirrorGlass{ir}: same arithmetic as the Rust dielectric */
         int front_face = !(v3_dot(r.dir, h->normal) > 0.0f);
@@ -449,8 +619,8 @@ static ray_t rust2_on_hit(const RtwSphere *s, const hit_t *h, ray_t r, rng_t *rn
 static v3 ray_color_rust2_rec(ctx_t *c, ray_t r, uint32_t depth) {
     if (depth == 0) return v3_ld(c->sc->background);
     hit_t h;
-    if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
-        const RtwSphere *sp = &c->sc->spheres[h.sphere];
+    if (closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn, c->rng)) {
+        const mat_t *sp = &h.mat;
         ray_t next = rust2_on_hit(sp, &h, r, c->rng, c->p->flags);   /* o.color(&h) draws nothing; o.reflect(&h) does */
         trace_record(c, 1, &h, NULL, r);
         v3 next_color = ray_color_rust2_rec(c, next, depth - 1);
@@ -465,11 +635,11 @@ static v3 ray_color_rust2_iter(ctx_t *c, ray_t r, uint32_t depth) {
     v3 thr = v3_make(1.0f, 1.0f, 1.0f), L = v3_make(0, 0, 0);
     for (uint32_t k = 0; k < depth; k++) {
         hit_t h;
-        if (!closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn)) {
+        if (!closest_hit(c->sc, r, c->p->mint, c->p->maxt, &h, c->cn, c->rng)) {
             trace_record(c, 0, NULL, NULL, r);
             return v3_add(L, v3_mul(v3_ld(c->sc->background), thr));
         }
-        const RtwSphere *sp = &c->sc->spheres[h.sphere];
+        const mat_t *sp = &h.mat;
         ray_t next = rust2_on_hit(sp, &h, r, c->rng, c->p->flags);
         trace_record(c, 1, &h, NULL, r);
         L = v3_add(L, v3_mul(v3_ld(sp->emitted), thr));
@@ -569,12 +739,12 @@ typedef struct {
     float *out; const uint32_t *rows; uint32_t n_rows;
     atomic_uint next;
     pthread_mutex_t mu;
-    uint64_t camera_rays, segments, sphere_tests; uint32_t nan_pixels;
+    uint64_t camera_rays, segments, sphere_tests, quad_tests; uint32_t nan_pixels;
 } job_t;
 
 static void *worker(void *arg) {
     job_t *jb = (job_t *)arg;
-    counters_t cn = { 0, 0 }; uint64_t rays = 0; uint32_t nans = 0;
+    counters_t cn = { 0, 0, 0 }; uint64_t rays = 0; uint32_t nans = 0;
     for (;;) {
         uint32_t k = atomic_fetch_add(&jb->next, 1);
         if (k >= jb->n_rows) break;
@@ -586,7 +756,7 @@ static void *worker(void *arg) {
         }
     }
     pthread_mutex_lock(&jb->mu);
-    jb->camera_rays += rays; jb->segments += cn.segments; jb->sphere_tests += cn.sphere_tests; jb->nan_pixels += nans;
+    jb->camera_rays += rays; jb->segments += cn.segments; jb->sphere_tests += cn.sphere_tests; jb->quad_tests += cn.quad_tests; jb->nan_pixels += nans;
     pthread_mutex_unlock(&jb->mu);
     return NULL;
 }
@@ -595,6 +765,13 @@ static int params_ok(const RtwCamera *cam, const RtwScene *sc, const RtwParams *
     if (!cam || !sc || !p) return 0;
     if (p->width == 0 || p->height == 0 || p->samples == 0) return 0;
     if (sc->n_spheres && !sc->spheres) return 0;
+    if ((sc->n_quads && !sc->quads) || (sc->n_instances && !sc->instances)) return 0;
+    if ((sc->n_inst_spheres && !sc->inst_spheres) || (sc->n_inst_quads && !sc->inst_quads)) return 0;
+    for (uint32_t i = 0; i < sc->n_instances; i++) {
+        const RtwInstance *in = &sc->instances[i];
+        if ((uint64_t)in->first_sphere + in->n_spheres > sc->n_inst_spheres) return 0;
+        if ((uint64_t)in->first_quad + in->n_quads > sc->n_inst_quads) return 0;
+    }
     if (p->integrator > RTW_INTEGRATOR_RUST2 || p->sampler > RTW_SAMPLER_NO_RAND) return 0;
     if (p->part_count > 1 && (p->row_block == 0 || p->part_index >= p->part_count)) return 0;
     return 1;
@@ -628,7 +805,7 @@ int rtw_oracle_render(const RtwCamera *cam, const RtwScene *sc, const RtwParams 
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (stats) {
         memset(stats, 0, sizeof *stats);
-        stats->camera_rays = jb.camera_rays; stats->segments = jb.segments; stats->sphere_tests = jb.sphere_tests;
+        stats->camera_rays = jb.camera_rays; stats->segments = jb.segments; stats->sphere_tests = jb.sphere_tests; stats->quad_tests = jb.quad_tests;
         stats->nan_pixels = jb.nan_pixels; stats->rows = n_rows;
         stats->total_ms = (float)((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
         stats->kernel_ms = stats->total_ms;
@@ -640,7 +817,7 @@ int rtw_oracle_trace_ray(const float origin[3], const float dir[3], float time,
                          const RtwScene *sc, const RtwParams *p, uint32_t pixel, uint32_t sample,
                          RtwOracleBounce *out, int cap, float rgb[3]) {
     if (!origin || !dir || !sc || !p) return RTW_E_INVALID;
-    counters_t cn = { 0, 0 };
+    counters_t cn = { 0, 0, 0 };
     rng_t rng = rng_seed(p->seed, pixel, sample);
     ctx_t c; memset(&c, 0, sizeof c); c.sc = sc; c.p = p; c.cn = &cn; c.rng = &rng;
     c.trace = out; c.trace_cap = cap;

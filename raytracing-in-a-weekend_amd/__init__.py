@@ -9,7 +9,10 @@ Reference surface mirrored (names and argument meaning):
   Viewport.new_from_res / Viewport.new      Rust/src/viewport.rs:308-428
   Viewport.render / async_render            Rust/src/viewport.rs:215-248,430-478
   Scene.new_sphere                          Rust/src/viewport.rs:90-105
+  Scene.new / new_quad                      Rust/src/viewport.rs:106-135
   Sphere.new / new_moving / new_with_texture Rust/src/objects/sphere.rs:151-247
+  Quad.new                                  Rust/src/objects/quad.rs:84-110
+  Instance.new / new_quads / new_sphere / new_box, translate, rotate   Rust/src/objects/instance.rs:83-248
   METALLIC_M, SCATTER_M, FUZZY3_M, GLASS_M, GLASSR_M   Rust/src/objects/materials.rs:157-212
 
 The directory name carries a hyphen (it is fixed by the build contract); import it with
@@ -33,7 +36,8 @@ INTEGRATOR_GRADIENT, INTEGRATOR_BG_COLOR, INTEGRATOR_NORMAL, INTEGRATOR_FLAG, IN
 SAMPLER_ROW, SAMPLER_STRATIFIED, SAMPLER_CENTRES, SAMPLER_NO_RAND = 0, 1, 2, 3
 ACCEL_BRUTE, ACCEL_BVH = 0, 1
 FLAG_RECURSIVE_ORDER, FLAG_CPP_DIELECTRIC, FLAG_GLOBAL_NODES = 1, 2, 4
-SCENE_C1, SCENE_C2, SCENE_C4, SCENE_C5, SCENE_METAL_TEST = 1, 2, 4, 5, 6
+SCENE_C1, SCENE_C2, SCENE_C4, SCENE_C5, SCENE_METAL_TEST, SCENE_QUAD_TEST, SCENE_PRESENTATION, SCENE_FIRST_FRAME = 1, 2, 4, 5, 6, 7, 8, 9
+MEDIUM_SURFACE, MEDIUM_CONST_DENSITY = 0, 1
 
 # materials.rs:157-212 presets as (metallicness, opacity, ir)
 METALLIC_M = (1.0, 0.0, 1.0)
@@ -68,10 +72,24 @@ class RtwTexture(C.Structure):
     _fields_ = [("row", C.c_uint32), ("col", C.c_uint32), ("texel_offset", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class RtwQuad(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("velocity", C.c_float * 3),
+                ("tex_color", C.c_float * 3), ("metallicness", C.c_float), ("opacity", C.c_float), ("ir", C.c_float),
+                ("emitted", C.c_float * 3), ("tex", C.c_int32)]
+
+
+class RtwInstance(C.Structure):
+    _fields_ = [("first_sphere", C.c_uint32), ("n_spheres", C.c_uint32), ("first_quad", C.c_uint32), ("n_quads", C.c_uint32),
+                ("translation", C.c_float * 3), ("rotation", C.c_float * 3), ("density", C.c_float), ("medium", C.c_uint32)]
+
+
 class RtwScene(C.Structure):
     _fields_ = [("spheres", C.POINTER(RtwSphere)), ("textures", C.POINTER(RtwTexture)),
                 ("texels", C.POINTER(C.c_float)), ("n_spheres", C.c_uint32), ("n_textures", C.c_uint32),
-                ("n_texels", C.c_uint32), ("background", C.c_float * 3)]
+                ("n_texels", C.c_uint32), ("background", C.c_float * 3),
+                ("quads", C.POINTER(RtwQuad)), ("instances", C.POINTER(RtwInstance)),
+                ("inst_spheres", C.POINTER(RtwSphere)), ("inst_quads", C.POINTER(RtwQuad)),
+                ("n_quads", C.c_uint32), ("n_instances", C.c_uint32), ("n_inst_spheres", C.c_uint32), ("n_inst_quads", C.c_uint32)]
 
 
 class RtwParams(C.Structure):
@@ -86,7 +104,7 @@ class RtwStats(C.Structure):
     _fields_ = [("camera_rays", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("node_tests", C.c_uint64), ("nan_pixels", C.c_uint32), ("rows", C.c_uint32),
                 ("kernel_ms", C.c_float), ("total_ms", C.c_float),
-                ("phase_steps", C.c_uint64 * 3), ("phase_lanes", C.c_uint64 * 3)]
+                ("phase_steps", C.c_uint64 * 3), ("phase_lanes", C.c_uint64 * 3), ("quad_tests", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k.startswith("phase_") else getattr(self, k)) for k, _ in self._fields_}
@@ -139,6 +157,10 @@ def lib() -> C.CDLL:
                                      C.POINTER(RtwTexture), C.c_uint32, C.POINTER(C.c_uint32),
                                      fp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.rtw_scene_default_view.argtypes = [C.c_uint32, C.POINTER(RtwCamera), C.POINTER(RtwParams)]
+    L.rtw_quad_new.argtypes = [fp, fp, fp, fp, fp, fp, C.POINTER(RtwQuad)]
+    L.rtw_box_quads.argtypes = [fp, fp, fp, fp, C.POINTER(RtwQuad)]
+    L.rtw_scene_generate_geom.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(RtwSphere), C.POINTER(RtwQuad), C.POINTER(RtwInstance),
+                                          C.POINTER(RtwSphere), C.POINTER(RtwQuad), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), fp]
     _lib = L
     return L
 
@@ -204,10 +226,66 @@ class Sphere:
         return sp
 
 
-class Scene:
-    """`Scene::new_sphere(spheres)` (Rust/src/viewport.rs:90-105): spheres (+ image textures)."""
+class Quad:
+    """`Quad` of Rust/src/objects/quad.rs:8-20; `new` is :84-110 with ImageTexture::from_color(color)."""
 
-    def __init__(self, spheres: Sequence, textures: Sequence[np.ndarray] = (), background=(0.0, 0.0, 0.0)):
+    def __init__(self, pod: RtwQuad):
+        self.pod = pod
+
+    @staticmethod
+    def new(origin, u, v, mat=None, color=(1.0, 1.0, 1.0), emitted=None, tex_index: int = -1) -> "Quad":
+        q = RtwQuad()
+        _check(lib().rtw_quad_new(_fptr(_f3(origin)), _fptr(_f3(u)), _fptr(_f3(v)), _fptr(_f3(mat)), _fptr(_f3(emitted)),
+                                  _fptr(_f3(color)), C.byref(q)), "rtw_quad_new")
+        q.tex = int(tex_index)
+        return Quad(q)
+
+
+class Instance:
+    """`Instance` of Rust/src/objects/instance.rs:27-38: member spheres and quads, translation, Euler rotation,
+    optional constant-density medium (`dist_fn = &const_density; density = d`)."""
+
+    def __init__(self, spheres: Sequence = (), quads: Sequence = ()):
+        self.spheres = [s.pod if isinstance(s, Sphere) else s for s in spheres]
+        self.quads = [q.pod if isinstance(q, Quad) else q for q in quads]
+        self.translation = [0.0, 0.0, 0.0]
+        self.rotation = [0.0, 0.0, 0.0]
+        self.density, self.medium = 0.0, MEDIUM_SURFACE
+
+    @staticmethod
+    def new(spheres, quads) -> "Instance":
+        return Instance(spheres, quads)
+
+    @staticmethod
+    def new_sphere(spheres) -> "Instance":
+        return Instance(spheres, ())
+
+    @staticmethod
+    def new_quads(quads) -> "Instance":
+        return Instance((), quads)
+
+    @staticmethod
+    def new_box(a, b, color, mat) -> "Instance":
+        """Instance::new_box (instance.rs:83-176) with ImageTexture::from_color(color)."""
+        q = (RtwQuad * 6)()
+        _check(lib().rtw_box_quads(_fptr(_f3(a)), _fptr(_f3(b)), _fptr(_f3(mat)), _fptr(_f3(color)), q), "rtw_box_quads")
+        return Instance((), [RtwQuad.from_buffer_copy(x) for x in q])
+
+    def translate(self, vec):                      # instance.rs:241-243 (f32 `+=`)
+        self.translation = [float(np.float32(a) + np.float32(b)) for a, b in zip(self.translation, vec)]
+
+    def rotate(self, rot):                         # instance.rs:234-236
+        self.rotation = [float(np.float32(a) + np.float32(b)) for a, b in zip(self.rotation, rot)]
+
+    def const_density(self, density: float):       # `x.dist_fn = &const_density; x.density = d` (main.rs:355-356)
+        self.density, self.medium = float(density), MEDIUM_CONST_DENSITY
+
+
+class Scene:
+    """`Scene` (Rust/src/viewport.rs:79-151): spheres (+ image textures), quads, instances, background colour."""
+
+    def __init__(self, spheres: Sequence, textures: Sequence[np.ndarray] = (), background=(0.0, 0.0, 0.0),
+                 quads: Sequence = (), instances: Sequence = ()):
         pods = [s.pod if isinstance(s, Sphere) else s for s in spheres]
         self._spheres = (RtwSphere * max(1, len(pods)))(*pods)
         self.n_spheres = len(pods)
@@ -229,10 +307,66 @@ class Scene:
         self.pod.n_spheres, self.pod.n_textures, self.pod.n_texels = self.n_spheres, self.n_textures, self.n_texels
         for k in range(3):
             self.pod.background[k] = float(background[k])
+        self._set_geom([q.pod if isinstance(q, Quad) else q for q in quads], list(instances))
+
+    def _set_geom(self, quads, instances):
+        """Flatten quads and instances into the ABI's pools (RtwScene.quads / instances / inst_spheres / inst_quads)."""
+        isph, iquad, inst = [], [], []
+        for it in instances:
+            if isinstance(it, Instance):
+                r = RtwInstance(len(isph), len(it.spheres), len(iquad), len(it.quads))
+                for k in range(3):
+                    r.translation[k], r.rotation[k] = it.translation[k], it.rotation[k]
+                r.density, r.medium = it.density, it.medium
+                isph += it.spheres
+                iquad += it.quads
+                inst.append(r)
+            else:                                   # (RtwInstance, member spheres, member quads) with absolute ranges
+                inst.append(it)
+        self._install_geom(quads, inst, isph, iquad)
+
+    def _install_geom(self, quads, inst, isph, iquad):
+        self._quads = (RtwQuad * max(1, len(quads)))(*quads)
+        self._instances = (RtwInstance * max(1, len(inst)))(*inst)
+        self._inst_spheres = (RtwSphere * max(1, len(isph)))(*isph)
+        self._inst_quads = (RtwQuad * max(1, len(iquad)))(*iquad)
+        self.pod.quads = C.cast(self._quads, C.POINTER(RtwQuad))
+        self.pod.instances = C.cast(self._instances, C.POINTER(RtwInstance))
+        self.pod.inst_spheres = C.cast(self._inst_spheres, C.POINTER(RtwSphere))
+        self.pod.inst_quads = C.cast(self._inst_quads, C.POINTER(RtwQuad))
+        self.pod.n_quads, self.pod.n_instances = len(quads), len(inst)
+        self.pod.n_inst_spheres, self.pod.n_inst_quads = len(isph), len(iquad)
+        self.n_quads, self.n_instances = len(quads), len(inst)
 
     @staticmethod
     def new_sphere(spheres: Sequence) -> "Scene":
         return Scene(spheres)
+
+    @staticmethod
+    def new_quad(quads: Sequence) -> "Scene":
+        """Scene::new_quad (viewport.rs:106-121)."""
+        return Scene((), quads=quads)
+
+    @staticmethod
+    def new(spheres: Sequence, quads: Sequence, instances: Sequence) -> "Scene":
+        """Scene::new(spheres, quads, instances) (viewport.rs:122-135); background_color is black."""
+        return Scene(spheres, quads=quads, instances=instances)
+
+    @staticmethod
+    def generate_geom(which: int, scene_seed: int = 42) -> "Scene":
+        """A scene with quads / instances laid out by the host library (SCENE_QUAD_TEST, SCENE_PRESENTATION)."""
+        L = lib()
+        counts = (C.c_uint32 * 5)()
+        bg = (C.c_float * 3)()
+        _check(L.rtw_scene_generate_geom(which, scene_seed, None, None, None, None, None, None, counts, bg), "rtw_scene_generate_geom")
+        n = [int(x) for x in counts]
+        sp, qd, ins = (RtwSphere * max(1, n[0]))(), (RtwQuad * max(1, n[1]))(), (RtwInstance * max(1, n[2]))()
+        isp, iqd = (RtwSphere * max(1, n[3]))(), (RtwQuad * max(1, n[4]))()
+        caps = (C.c_uint32 * 5)(*n)
+        _check(L.rtw_scene_generate_geom(which, scene_seed, sp, qd, ins, isp, iqd, caps, counts, bg), "rtw_scene_generate_geom")
+        sc = Scene(list(sp)[:n[0]], background=tuple(bg))
+        sc._install_geom(list(qd)[:n[1]], list(ins)[:n[2]], list(isp)[:n[3]], list(iqd)[:n[4]])
+        return sc
 
     def to_json(self) -> str:
         """`Into<JsonValue> for Scene` (Rust/src/viewport.rs:174-180)."""

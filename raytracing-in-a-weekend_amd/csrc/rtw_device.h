@@ -13,6 +13,9 @@
 //   Rust/src/objects/materials.rs:89-154   refract, reflectance, Material::on_hit (+ diffuse :213-228)
 //   Rust/src/viewport/ray_color.rs:12-92   ray_color_gradient / ray_color_bg_color
 //   Rust/src/texture.rs:259-267            ImageTexture::color_at
+//   Rust/src/objects/quad.rs:37-81         Quad::collision_normal
+//   Rust/src/objects/instance.rs:250-310   Instance::collision_normal (+ const_density :24-26)
+//   Rust/src/vec3.rs:161-181               Vec3::rotated
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -121,6 +124,38 @@ struct DevScene {
     uint32_t moving;
 };
 
+// `Quad` with the derived fields of Quad::new (quad.rs:96-108), seven 16-byte rows read by scalar loads.
+struct DevQuad {
+    float origin[3]; float d;             // d = normal . origin
+    float u[3];      float metallicness;
+    float v[3];      float opacity;
+    float normal[3]; float ir;            // unit(u x v)
+    float w[3];      int32_t tex;         // n / (n . n)
+    float albedo[3]; uint32_t pad0;       // tex < 0: the 1x1 texel * 1.0 (texture.rs:265)
+    float emitted[3]; uint32_t pad1;
+};
+static_assert(sizeof(DevQuad) == 112, "DevQuad is seven f4 rows");
+
+// `Instance` (instance.rs:27-38): member ranges, translation, and sin/cos of -rotation / +rotation
+// (Vec3::rotated recomputes them per call, vec3.rs:163-170; hoisted to the host, same libm).
+struct DevInstance {
+    uint32_t first_sphere, n_spheres, first_quad, n_quads;
+    float tr[3]; float density;
+    float back[6]; float fwd[6];          // asin, acos, bsin, bcos, csin, ccos
+    uint32_t medium; uint32_t pad[3];
+};
+static_assert(sizeof(DevInstance) == 96, "DevInstance is six f4 rows");
+
+struct DevGeom {                          // everything of `Scene` that is not a top-level sphere
+    const DevQuad *quads;
+    const DevInstance *inst;
+    const f4 *igeom;                      // instance-member spheres: same three streams as DevScene
+    const f4 *ivel;
+    const DevMat *imat;
+    const DevQuad *iquads;
+    uint32_t n_quads, n_inst;
+};
+
 // Rust `f as usize` (saturating, NaN -> 0), then clamped to the image like the oracle
 __device__ __forceinline__ uint32_t tex_index(float f, uint32_t last) {
     if (!(f > 0.0f)) return 0;
@@ -161,7 +196,8 @@ __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
 
 // Material::on_hit (materials.rs:105-154) followed by the degenerate-direction fix-up of
 // ray_color_* (ray_color.rs:31-33).  Returns the next direction; cos_theta for bg_color.
-__device__ __forceinline__ v3 on_hit(const DevMat &m, v3 normal, v3 dir, Rng &rng, float &cos_theta) {
+struct MatP { float metallicness, opacity, ir; };   // the scalars of `Material` on_hit reads (materials.rs:15-20)
+__device__ __forceinline__ v3 on_hit(const MatP m, v3 normal, v3 dir, Rng &rng, float &cos_theta) {
     const bool front = !(dot(dir, normal) > 0.0f);
     // Shared by both branches: unit(dir), and its mirror direction.  reflect(ud, -n) == reflect(ud, n)
     // bit for bit ((-n*2) * dot(ud,-n) == (n*2) * dot(ud,n): negation is exact and commutes with the
@@ -194,7 +230,7 @@ __device__ __forceinline__ v3 on_hit(const DevMat &m, v3 normal, v3 dir, Rng &rn
 // Rust2's Material trait objects (Rust2/src/objects/material.rs): MirrorGlass :130-162 (the Rust
 // dielectric's arithmetic), Mirror :75-83 (reflects the un-normalised direction), Lambertian :25-36
 // (unit(n + random_unit_vec())).  No degenerate-direction fix-up in Rust2's ray_color.
-__device__ __forceinline__ v3 on_hit_rust2(const DevMat &m, v3 normal, v3 dir, Rng &rng) {
+__device__ __forceinline__ v3 on_hit_rust2(const MatP m, v3 normal, v3 dir, Rng &rng) {
     if (m.opacity > 0.0f) {
         const bool front = !(dot(dir, normal) > 0.0f);
         const v3 n = front ? normal : -normal;
@@ -211,6 +247,157 @@ __device__ __forceinline__ v3 on_hit_rust2(const DevMat &m, v3 normal, v3 dir, R
     }
     if (m.metallicness == 1.0f) return reflect(dir, normal);
     return unit(normal + random_unit_vec(rng));
+}
+
+// ---- quads and instances ----------------------------------------------------------
+// What a closest-hit query reports when the winner is not a top-level sphere: `Hit` (objects.rs:16-23).
+struct GeomHit {
+    float t;
+    v3 point, normal, cm;
+    MatP m;
+    v3 emitted;
+};
+
+// Vec3::rotated (vec3.rs:161-181) as written; q = {asin, acos, bsin, bcos, csin, ccos}
+__device__ __forceinline__ v3 rotated(v3 a, const float *q) {
+    const float as = q[0], ac = q[1], bs = q[2], bc = q[3], cs = q[4], cc = q[5];
+    v3 o;
+    o.x = a.x * bc * cc + a.y * (as * bs * cc - as * cc) + a.z * (ac * bs * cc + as * cs);
+    o.y = a.x * bc * cs + a.y * (as * bs * cs + ac * cc) + a.z * (ac * bs * cs - as * cc);
+    o.z = a.x * -bs + a.y * as * bc + a.z * ac * bc;
+    return o;
+}
+
+// ln(x), x a positive normal f32: f64 atanh series, rounded once.  The same operations as oracle/rtw_oracle.c
+// ln_f32 (f64 add/mul/div are IEEE on both sides, no contraction), correctly rounded for every xi = k 2^-24.
+__device__ __forceinline__ float ln_f32(float xf) {
+    if (xf == 0.0f) return -__builtin_inff();
+    const uint32_t bits = __builtin_bit_cast(uint32_t, xf);
+    int e = (int)(bits >> 23) - 127;
+    const float mf = __builtin_bit_cast(float, (bits & 0x007FFFFFu) | 0x3F800000u);
+    double m = (double)mf;
+    if (mf > 1.41421354f) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 1.0 / 25.0;
+    p = 1.0 / 23.0 + z * p; p = 1.0 / 21.0 + z * p; p = 1.0 / 19.0 + z * p; p = 1.0 / 17.0 + z * p;
+    p = 1.0 / 15.0 + z * p; p = 1.0 / 13.0 + z * p; p = 1.0 / 11.0 + z * p; p = 1.0 / 9.0 + z * p;
+    p = 1.0 / 7.0 + z * p;  p = 1.0 / 5.0 + z * p;  p = 1.0 / 3.0 + z * p;
+    const double lm = 2.0 * s + (2.0 * s) * (z * p);
+    return (float)((double)e * 0.6931471805599453094 + lm);
+}
+
+// Quad::collision_normal (quad.rs:37-81) against quad `qi` of `quads`; on Some(hit) that is strictly closer
+// than the current one (`min_hit == None || min_hit > i`) it replaces h.
+__device__ __forceinline__ void quad_test(const DevScene &sc, const DevQuad *quads, uint32_t qi, v3 o, v3 d,
+                                          float mint, float maxt, bool &found, GeomHit &h) {
+    cf4_ptr q = (cf4_ptr)(uintptr_t)(quads + qi);
+    const f4 r0 = q[0], r3 = q[3];
+    const v3 normal = mk(r3.x, r3.y, r3.z);
+    const float denominator = dot(normal, d);
+    if (__builtin_fabsf(denominator) <= 1e-8f) return;
+    const float t = (r0.w - dot(normal, o)) / denominator;
+    if (t < mint || t > maxt) return;
+    const f4 r1 = q[1], r2 = q[2], r4 = q[4];
+    const v3 point = o + d * t;
+    const v3 planar = point - mk(r0.x, r0.y, r0.z);
+    const v3 qu = mk(r1.x, r1.y, r1.z), qv = mk(r2.x, r2.y, r2.z), w = mk(r4.x, r4.y, r4.z);
+    const v3 pxv = mk(planar.y * qv.z - planar.z * qv.y, planar.z * qv.x - planar.x * qv.z, planar.x * qv.y - planar.y * qv.x);
+    const v3 uxp = mk(qu.y * planar.z - qu.z * planar.y, qu.z * planar.x - qu.x * planar.z, qu.x * planar.y - qu.y * planar.x);
+    const float alfa = dot(w, pxv), beta = dot(w, uxp);
+    if (alfa < 0.0f || alfa > 1.0f || beta < 0.0f || beta > 1.0f) return;
+    if (found && !(h.t > t)) return;
+    const f4 r5 = q[5], r6 = q[6];
+    const int32_t tex = __builtin_bit_cast(int32_t, r4.w);
+    v3 cm = mk(r5.x, r5.y, r5.z);
+    if (tex >= 0) {                                            // quad.rs:64-79
+        const RtwTexture tx = sc.tex[tex];
+        const uint32_t ix = alfa != 1.0f ? tex_index(floorf(alfa * (float)tx.row), tx.row - 1) : tx.row - 1;
+        const uint32_t iy = beta != 1.0f ? tex_index(floorf(beta * (float)tx.col), tx.col - 1) : tx.col - 1;
+        cm = ld3(sc.texels + 3 * (size_t)(tx.texel_offset + iy * tx.row + ix)) * 1.0f;
+    }
+    found = true;
+    h.t = t; h.point = point; h.normal = normal; h.cm = cm;
+    h.m.metallicness = r1.w; h.m.opacity = r2.w; h.m.ir = r3.w;
+    h.emitted = mk(r6.x, r6.y, r6.z);
+}
+
+// Closest member of an instance: its spheres in list order, then its quads (instance.rs:263-273).
+__device__ __forceinline__ bool instance_members(const DevScene &sc, const DevGeom &g, const DevInstance &in, v3 o, v3 d, float tm,
+                                                 float mint, float maxt, GeomHit &h, uint32_t &n_sph, uint32_t &n_quad) {
+    bool found = false;
+    int best = -1; float best_t = 0.0f;
+    const float a = dot(d, d);
+    cf4_ptr geom = (cf4_ptr)(uintptr_t)g.igeom, vel = (cf4_ptr)(uintptr_t)g.ivel;
+    for (uint32_t k = 0; k < in.n_spheres; ++k) {              // sphere.rs:99-147, as closest_brute
+        const uint32_t s = in.first_sphere + k;
+        const f4 gg = geom[s], vv = vel[s];
+        const float cx = gg.x + vv.x * tm, cy = gg.y + vv.y * tm, cz = gg.z + vv.z * tm;
+        const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+        const float b = ocx * d.x + ocy * d.y + ocz * d.z;
+        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - gg.w;
+        const float disc = b * b - a * c;
+        if (!(disc < 0.0f)) {
+            const float sq = __builtin_sqrtf(disc);
+            float x = (-b - sq) / a;
+            if (x < mint) x = (-b + sq) / a;
+            if (!(x < mint || x > maxt)) {
+                if (best < 0 || best_t > x) { best = (int)s; best_t = x; }
+            }
+        }
+    }
+    n_sph += in.n_spheres;
+    if (best >= 0) {
+        const f4 gg = g.igeom[best], vv = g.ivel[best];
+        const v3 c = mk(gg.x, gg.y, gg.z) + mk(vv.x, vv.y, vv.z) * tm;
+        const DevMat mat = g.imat[best];
+        found = true;
+        h.t = best_t; h.point = o + d * best_t; h.normal = unit(h.point - c);
+        h.cm = sphere_albedo(sc, mat, h.normal);
+        h.m.metallicness = mat.metallicness; h.m.opacity = mat.opacity; h.m.ir = mat.ir;
+        h.emitted = ld3(mat.emitted);
+    }
+    for (uint32_t k = 0; k < in.n_quads; ++k) quad_test(sc, g.iquads, in.first_quad + k, o, d, mint, maxt, found, h);
+    n_quad += in.n_quads;
+    return found;
+}
+
+// The part of Scene::collision_normal (viewport.rs:136-150) after the top-level spheres: quads, then instances.
+// `found`/`h.t` enter as the sphere result (h.t = its t); returns true when a quad or an instance wins.
+__device__ __forceinline__ bool geom_closest(const DevScene &sc, const DevGeom &g, v3 o, v3 d, float tm, float mint, float maxt,
+                                             bool sphere_found, float sphere_t, Rng &rng, GeomHit &h, uint32_t &n_sph, uint32_t &n_quad) {
+    bool found = sphere_found, won = false;
+    h.t = sphere_t;
+    {   // q_hit: closest quad first, then compared with s_hit
+        GeomHit qh; bool qfound = false;
+        for (uint32_t k = 0; k < g.n_quads; ++k) quad_test(sc, g.quads, k, o, d, mint, maxt, qfound, qh);
+        n_quad += g.n_quads;
+        if (qfound && (!found || h.t > qh.t)) { h = qh; found = true; won = true; }
+    }
+    GeomHit ih; bool ifound = false;
+    for (uint32_t i = 0; i < g.n_inst; ++i) {                 // Instance::collision_normal (instance.rs:250-310)
+        const DevInstance in = g.inst[i];
+        const v3 tr = ld3(in.tr);
+        const v3 lo = rotated(o - tr, in.back), ld = rotated(d, in.back);
+        GeomHit c;
+        if (!instance_members(sc, g, in, lo, ld, tm, mint, maxt, c, n_sph, n_quad)) continue;
+        if (in.medium == RTW_MEDIUM_CONST_DENSITY) {           // const_density (:24-26)
+            const float distance = ln_f32(rng_f32(rng)) / -in.density;
+            if (distance >= 0.0f) {
+                const v3 o2 = c.point + ld * distance;
+                GeomHit second;
+                if (!instance_members(sc, g, in, o2, ld, tm, mint, maxt, second, n_sph, n_quad)) continue;   // left the volume first
+                c.point = o2;
+                c.normal = random_unit_vec(rng);
+            }
+        }
+        c.point = rotated(c.point, in.fwd) + tr;
+        c.normal = rotated(c.normal, in.fwd);
+        if (!ifound || ih.t > c.t) { ih = c; ifound = true; }
+    }
+    if (ifound && (!found || h.t > ih.t)) { h = ih; won = true; }
+    return won;
 }
 
 // ray_color.rs:38-40

@@ -9,6 +9,10 @@
 #include <cstring>
 #include <limits>
 
+// The ABI's PODs have no implicit padding (the ctypes / Rust mirrors rely on these sizes).
+static_assert(sizeof(RtwCamera) == 84 && sizeof(RtwSphere) == 80 && sizeof(RtwTexture) == 16 && sizeof(RtwQuad) == 88, "POD layout");
+static_assert(sizeof(RtwInstance) == 48 && sizeof(RtwScene) == 96 && sizeof(RtwParams) == 72 && sizeof(RtwStats) == 104, "POD layout");
+
 namespace rtw {
 
 uint32_t sampler_count(uint32_t sampler, uint32_t samples, uint32_t *s_root) {
@@ -205,6 +209,38 @@ int rtw_sphere_new_with_texture(const float origin[3], float radius, const float
     return RTW_OK;
 }
 
+int rtw_quad_new(const float origin[3], const float u[3], const float v[3], const float *mat3,
+                 const float *emitted, const float color[3], RtwQuad *out) {
+    if (!origin || !u || !v || !color || !out) return RTW_E_INVALID;
+    std::memset(out, 0, sizeof *out);
+    const float *m = mat3 ? mat3 : SCATTER_M;
+    for (int k = 0; k < 3; k++) {
+        out->origin[k] = origin[k]; out->u[k] = u[k]; out->v[k] = v[k];
+        out->tex_color[k] = color[k];                    // ImageTexture::from_color
+        out->emitted[k] = emitted ? emitted[k] : 0.0f;
+    }
+    out->metallicness = m[0]; out->opacity = m[1]; out->ir = m[2];
+    out->tex = -1;
+    return RTW_OK;
+}
+
+// Instance::new_box (instance.rs:83-176): front, right, back, left, top, bottom
+int rtw_box_quads(const float a[3], const float b[3], const float *mat3, const float color[3], RtwQuad q[6]) {
+    if (!a || !b || !color || !q) return RTW_E_INVALID;
+    const V lo = mk(a[0] <= b[0] ? a[0] : b[0], a[1] <= b[1] ? a[1] : b[1], a[2] <= b[2] ? a[2] : b[2]);   // minf / maxf (objects.rs:81-86)
+    const V hi = mk(a[0] >= b[0] ? a[0] : b[0], a[1] >= b[1] ? a[1] : b[1], a[2] >= b[2] ? a[2] : b[2]);
+    const V dx = mk(hi.x - lo.x, 0, 0), dy = mk(0, hi.y - lo.y, 0), dz = mk(0, 0, hi.z - lo.z);
+    const V org[6] = { mk(lo.x, lo.y, hi.z), mk(hi.x, lo.y, hi.z), mk(hi.x, lo.y, lo.z), mk(lo.x, lo.y, lo.z), mk(lo.x, hi.y, hi.z), mk(lo.x, lo.y, lo.z) };
+    const V uu[6] = { dx, -dz, -dx, dz, dx, dx };
+    const V vv[6] = { dy, dy, dy, dy, -dz, dz };
+    for (int k = 0; k < 6; k++) {
+        float o3[3], u3[3], v3[3]; st(o3, org[k]); st(u3, uu[k]); st(v3, vv[k]);
+        int rc = rtw_quad_new(o3, u3, v3, mat3, nullptr, color, &q[k]);
+        if (rc != RTW_OK) return rc;
+    }
+    return RTW_OK;
+}
+
 // ---- scene generators.  None of these scenes exists in the reference; they are
 // expressed with the reference's Sphere::new / material presets. ------------------------------------
 static void book1_small_spheres(Pcg32 &rng, std::vector<RtwSphere> &out, bool moving) {
@@ -251,6 +287,18 @@ int rtw_scene_generate(uint32_t which, uint64_t scene_seed,
         sp.push_back(sphere_new(mk(0, 0, -1), 0.5f, mk(0.7f, 0.3f, 0.3f), SCATTER_M));
         sp.push_back(sphere_new(mk(0, -100.5f, -1), 100.0f, mk(0.8f, 0.8f, 0.0f), SCATTER_M));
         break;
+    case RTW_SCENE_FIRST_FRAME: { // main.rs:427-496, the scene of Rust/First frame.png
+        sp.push_back(sphere_new(mk(-0.8f, 0, -1.0f), 0.4f, mk(1.0f, 0.6f, 0.6f), FUZZY3_M));
+        sp.push_back(sphere_new(mk(0.6f, 0, -1.2f), 0.3f, mk(0.5f, 0.9f, 0.9f), METALLIC_M));
+        RtwSphere mv = sphere_new(mk(2.4f, 0, -0.8f), 1.4f, mk(0.9f, 0.9f, 0.9f), METALLIC_M);   // Sphere::new_moving(.., (0, 60, 0))
+        mv.velocity[1] = 60.0f;
+        sp.push_back(mv);
+        sp.push_back(sphere_new(mk(0, 0, -0.7f), 0.3f, mk(1, 1, 1), GLASS_M));
+        sp.push_back(sphere_new(mk(0, 0, -0.7f), 0.2f, mk(1, 1, 1), GLASSR_M));
+        sp.push_back(sphere_new(mk(0, 0, -2.0f), 1.0f, mk(0.5f, 1.0f, 0.0f), SCATTER_M));
+        sp.push_back(sphere_new(mk(0, -1000.9f, -5.0f), 1000.0f, mk(0.8f, 0.5f, 1.0f), SCATTER_M));
+        break;
+    }
     case RTW_SCENE_C2_BOOK1_FINAL:
         sp.push_back(sphere_albedo(mk(0, -1000, 0), 1000.0f, mk(0.5f, 0.5f, 0.5f), SCATTER_M));
         book1_small_spheres(rng, sp, false);
@@ -297,6 +345,79 @@ int rtw_scene_generate(uint32_t which, uint64_t scene_seed,
     return RTW_OK;
 }
 
+static RtwQuad quad_of(V o, V u, V v, const float *mat3, V color, const float *emitted = nullptr) {
+    RtwQuad q; float o3[3], u3[3], v3[3], c3[3]; st(o3, o); st(u3, u); st(v3, v); st(c3, color);
+    rtw_quad_new(o3, u3, v3, mat3, emitted, c3, &q);
+    return q;
+}
+
+int rtw_scene_generate_geom(uint32_t which, uint64_t scene_seed, RtwSphere *spheres, RtwQuad *quads,
+                            RtwInstance *instances, RtwSphere *inst_spheres, RtwQuad *inst_quads,
+                            const uint32_t caps[5], uint32_t counts[5], float background[3]) {
+    std::vector<RtwSphere> sp, isp; std::vector<RtwQuad> qd, iqd; std::vector<RtwInstance> in;
+    if (background) background[0] = background[1] = background[2] = 0.0f;        // Scene::new (viewport.rs:131-135)
+    const float PI = 3.14159265358979323846f;
+    switch (which) {
+    case RTW_SCENE_QUAD_TEST:         // objects/quad.rs:152-299: red, green, blue, orange, teal
+        qd.push_back(quad_of(mk(-3, -2, 5), mk(0, 0, -4), mk(0, 4, 0), SCATTER_M, mk(1.0f, 0.2f, 0.2f)));
+        qd.push_back(quad_of(mk(-2, -2, 0), mk(4, 0, 0), mk(0, 4, 0), SCATTER_M, mk(0.2f, 1.0f, 0.2f)));
+        qd.push_back(quad_of(mk(3, -2, 1), mk(0, 0, 4), mk(0, 4, 0), SCATTER_M, mk(0.2f, 0.2f, 1.0f)));
+        qd.push_back(quad_of(mk(-2, 3, 1), mk(4, 0, 0), mk(0, 0, 4), SCATTER_M, mk(1.0f, 0.5f, 0.0f)));
+        qd.push_back(quad_of(mk(-2, -3, 5), mk(4, 0, 0), mk(0, 0, -4), SCATTER_M, mk(0.2f, 0.8f, 0.8f)));
+        break;
+    case RTW_SCENE_PRESENTATION: {    // main.rs:89-419
+        sp.push_back(sphere_new(mk(-1.6f, -1.6f, 3.0f), 0.4f, mk(1, 0, 0), SCATTER_M));
+        const float light[3] = { 4, 4, 4 }, dark[3] = { 0, 0, 0 };
+        const float emit_m[3] = { 0.0f, 0.0f, 1.0f };                                     // Material::new_emmiting(0, 0, 1, ..)
+        qd.push_back(quad_of(mk(-2, -2, 5), mk(0, 0, -4), mk(0, 4, 0), METALLIC_M, mk(0.85f, 0.85f, 0.85f)));        // "Red": a mirror wall
+        qd.push_back(quad_of(mk(-1.5f, -1.5f, 1.001f), mk(3, 0, 0), mk(0, 3, 0), emit_m, mk(1, 1, 1), light));   // Light
+        qd.push_back(quad_of(mk(2, -2, 1), mk(0, 0, 4), mk(0, 4, 0), SCATTER_M, mk(0.2f, 0.2f, 1.0f)));             // Blue
+        qd.push_back(quad_of(mk(-2, 2, 1), mk(4, 0, 0), mk(0, 0, 4), SCATTER_M, mk(1.0f, 0.5f, 0.0f)));             // Orange
+        qd.push_back(quad_of(mk(-2, -2, 5), mk(4, 0, 0), mk(0, 0, -4), SCATTER_M, mk(0.2f, 0.8f, 0.8f)));           // Teal
+        qd.push_back(quad_of(mk(-2, -2, 1), mk(4, 0, 0), mk(0, 4, 0), emit_m, mk(0.2f, 1.0f, 0.2f), dark));        // Green
+        // smoke: Instance::new_box((-1,-.5,-.5), (1,.5,.5), 0.2 grey, SCATTER_M), translate (0,-1.5,2), rotate y pi/4, density 2
+        RtwInstance smoke; std::memset(&smoke, 0, sizeof smoke);
+        const float ba[3] = { -1.0f, -0.5f, -0.5f }, bb[3] = { 1.0f, 0.5f, 0.5f }, grey[3] = { 0.2f, 0.2f, 0.2f };
+        RtwQuad box[6]; rtw_box_quads(ba, bb, SCATTER_M, grey, box);
+        smoke.first_quad = 0; smoke.n_quads = 6; iqd.insert(iqd.end(), box, box + 6);
+        smoke.translation[0] = -0.0f; smoke.translation[1] = -1.5f; smoke.translation[2] = 2.0f;
+        smoke.rotation[1] = PI / 4.0f;
+        smoke.medium = RTW_MEDIUM_CONST_DENSITY; smoke.density = 2.0f;
+        in.push_back(smoke);
+        // glass pane: two coincident-ish quads, ir 1.5 and 2/3 (opacity 0.8 only selects the dielectric branch)
+        RtwInstance glass; std::memset(&glass, 0, sizeof glass);
+        const float g1[3] = { 1.0f, 0.8f, 1.50f }, g2[3] = { 1.0f, 0.8f, 2.0f / 3.0f };
+        glass.first_quad = 6; glass.n_quads = 2;
+        iqd.push_back(quad_of(mk(0, 0, 0), mk(0, 4, 0), mk(2, 0, 0), g1, mk(0.8f, 0.8f, 0.8f)));
+        iqd.push_back(quad_of(mk(0, 0, -0.001f), mk(0, 4, 0), mk(2, 0, 0), g2, mk(0.8f, 0.8f, 0.8f)));
+        glass.translation[0] = 2.0f - std::sqrt(3.0f); glass.translation[1] = -2.0f; glass.translation[2] = 3.0f;
+        glass.rotation[1] = -PI / 6.0f;
+        in.push_back(glass);
+        break;
+    }
+    default: {                        // the sphere-only scenes
+        uint32_t n = 0, nt = 0, nl = 0;
+        int rc = rtw_scene_generate(which, scene_seed, nullptr, 0, &n, nullptr, 0, &nt, nullptr, 0, &nl);
+        if (rc != RTW_OK) return rc;
+        if (nt) return RTW_E_INVALID;                 // textured scenes go through rtw_scene_generate
+        sp.resize(n);
+        rc = rtw_scene_generate(which, scene_seed, sp.data(), n, &n, nullptr, 0, &nt, nullptr, 0, &nl);
+        if (rc != RTW_OK) return rc;
+    }
+    }
+    const size_t n5[5] = { sp.size(), qd.size(), in.size(), isp.size(), iqd.size() };
+    if (counts) for (int k = 0; k < 5; k++) counts[k] = (uint32_t)n5[k];
+    void *dst[5] = { spheres, quads, instances, inst_spheres, inst_quads };
+    const void *src[5] = { sp.data(), qd.data(), in.data(), isp.data(), iqd.data() };
+    const size_t esz[5] = { sizeof(RtwSphere), sizeof(RtwQuad), sizeof(RtwInstance), sizeof(RtwSphere), sizeof(RtwQuad) };
+    for (int k = 0; k < 5; k++) {
+        if (!dst[k] || n5[k] == 0) continue;
+        if (!caps || caps[k] < n5[k]) return RTW_E_INVALID;
+        std::memcpy(dst[k], src[k], n5[k] * esz[k]);
+    }
+    return RTW_OK;
+}
+
 int rtw_scene_default_view(uint32_t which, RtwCamera *cam, RtwParams *p) {
     if (!cam || !p) return RTW_E_INVALID;
     std::memset(p, 0, sizeof *p);
@@ -309,6 +430,22 @@ int rtw_scene_default_view(uint32_t which, RtwCamera *cam, RtwParams *p) {
         p->samples = which == RTW_SCENE_METAL_TEST ? 100 : 10;
         if (which == RTW_SCENE_METAL_TEST) { p->sampler = RTW_SAMPLER_STRATIFIED; p->maxt = 1000.0f; }   // viewport.render(&ray_color_d) material_tests.rs:165
         return rtw_viewport_new_from_res(p->width, p->height, nullptr, nullptr, nullptr, nullptr, nullptr, cam, &h);
+    }
+    if (which == RTW_SCENE_FIRST_FRAME) {        // main.rs:497-545: 400x400, 100 spp, depth 100, frame 0 at 15 fps, shutter 0, test_run(.., ray_color_d, ..)
+        p->width = 400; p->height = 400; p->samples = 100; p->depth = 100; p->maxt = 1000.0f;
+        return rtw_viewport_new_from_res(p->width, p->height, nullptr, nullptr, nullptr, nullptr, nullptr, cam, &h);
+    }
+    if (which == RTW_SCENE_QUAD_TEST) {          // quad.rs:277-298: 400x400, 100 spp, depth 10, vfov 80 from (0,0,9), viewport.render(&ray_color_d)
+        const float vf = 80.0f, from9[3] = { 0, 0, 9 }, fwd[3] = { 0, 0, -1 };
+        p->width = 400; p->height = 400; p->samples = 100; p->depth = 10;
+        p->sampler = RTW_SAMPLER_STRATIFIED; p->maxt = 1000.0f;
+        return rtw_viewport_new_from_res(p->width, p->height, &vf, from9, fwd, nullptr, nullptr, cam, &h);
+    }
+    if (which == RTW_SCENE_PRESENTATION) {       // main.rs:386-417: 400x400, 2500 spp, depth 20, vfov 90 from (0,0,7), async_render(&ray_color_bg_color)
+        const float vf = 90.0f, from7[3] = { 0, -0.0f, 7 }, fwd[3] = { 0, 0, -1 };
+        p->width = 400; p->height = 400; p->samples = 2500; p->depth = 20;
+        p->integrator = RTW_INTEGRATOR_BG_COLOR; p->maxt = 10000.0f;     // ray_color.rs:48-49
+        return rtw_viewport_new_from_res(p->width, p->height, &vf, from7, fwd, nullptr, nullptr, cam, &h);
     }
     // Book-1 framing: look from (13,2,3) at the origin, vfov 20, aperture 0.1 (lens_radius 0.05).
     // The reference does not normalise `direction`: w = -direction and v = w x u inherit its length

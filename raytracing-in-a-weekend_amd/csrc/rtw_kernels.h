@@ -29,6 +29,7 @@ struct KArgs {
     RtwCamera cam;
     DevScene  sc;
     DevBvh    bvh;
+    DevGeom   geom;               // quads and instances (n_quads == n_inst == 0 for sphere-only scenes)
     uint32_t width, height;       // full image
     uint32_t k_base, k_end;       // compact rows [k_base, k_end) of this partition rendered by this launch (a band)
     uint32_t n_tiles;             // tiles_x * ceil((k_end - k_base) / 8)
@@ -48,7 +49,7 @@ struct KArgs {
     float bg[3];
     float *out;                   // [rows of the partition][width][3]
     uint32_t *queue;              // work-item counter, zeroed before launch
-    unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels [5..7] phase steps [8..10] phase lanes
+    unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels [5..7] phase steps [8..10] phase lanes [14] quad tests
 };
 
 // accel: RTW_ACCEL_BRUTE, RTW_ACCEL_BVH; the BVH launch picks the LDS-resident variant when a.bvh.nodes16 != null

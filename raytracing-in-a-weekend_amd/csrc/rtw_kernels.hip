@@ -149,17 +149,10 @@ __device__ __forceinline__ void shade_miss(const KArgs &A, Path &pt) {
     pt.L = pt.L + miss * pt.thr;
 }
 
-// One step of ray_color_* at the closest hit (best >= 0, best_t).  Returns true when the path is finished
-// (pt.L is then its radiance).
-template <bool MOVING, int SPEC>
-__device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, float best_t) {
-    const DevScene &sc = A.sc;
-    f4 g = sc.geom[best];
-    v3 c = mk(g.x, g.y, g.z);
-    if (MOVING) { f4 vv = sc.vel[best]; c = c + mk(vv.x, vv.y, vv.z) * pt.tm; }
-    const v3 point = pt.o + pt.d * best_t;                   // r.at(x)
-    const v3 normal = unit(point - c);                       // sphere.rs:127
-    const DevMat mat = sc.mat[best];
+// One step of ray_color_* at the closest hit, given as the reference's `Hit` (objects.rs:16-23): point, normal,
+// col_mod, material.  Returns true when the path is finished (pt.L is then its radiance).
+template <int SPEC>
+__device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 point, v3 normal, v3 cm, MatP mat, v3 emitted) {
     if (integ<SPEC>(A) == RTW_INTEGRATOR_NORMAL) {             // C++/src/tests.cpp:91
         pt.L = mk(normal.x + 1.0f, normal.y + 1.0f, normal.z + 1.0f) * 0.5f;
         return true;
@@ -168,10 +161,9 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, fl
         pt.L = mk(1.0f, 1.0f, 0.0f) * pt.thr;                // glass_tests.rs:35-37
         return true;
     }
-    const v3 cm = SPEC == 1 ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
     if (integ<SPEC>(A) == RTW_INTEGRATOR_RUST2) {              // Rust2/src/viewport/ray_color.rs:17-31, front-to-back
         const v3 nd2 = on_hit_rust2(mat, normal, pt.d, pt.rng);
-        pt.L = pt.L + ld3(mat.emitted) * pt.thr;
+        pt.L = pt.L + emitted * pt.thr;
         pt.thr = pt.thr * cm;
         pt.o = point; pt.d = nd2;
         pt.k++;
@@ -184,7 +176,7 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, fl
         // lambertian_scatter_pdf (materials.rs:5-13); pdf == 0 makes the reference's `color * pdf / pdf` a 0/0
         const float pdf = cos_theta > 0.0f ? cos_theta * 0.318309886183790671538f : 0.0f;
         if (mat.metallicness != 1.0f && !(pdf > 0.0f)) pt.poison = true;
-        pt.L = pt.L + ld3(mat.emitted) * pt.thr;
+        pt.L = pt.L + emitted * pt.thr;
     }
     pt.thr = pt.thr * cm;
     pt.o = point; pt.d = nd;
@@ -196,10 +188,35 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, fl
     return false;
 }
 
+// ... at top-level sphere `best` (Sphere::collision_normal's Hit, sphere.rs:124-146).
+template <bool MOVING, int SPEC>
+__device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, float best_t) {
+    const DevScene &sc = A.sc;
+    f4 g = sc.geom[best];
+    v3 c = mk(g.x, g.y, g.z);
+    if (MOVING) { f4 vv = sc.vel[best]; c = c + mk(vv.x, vv.y, vv.z) * pt.tm; }
+    const v3 point = pt.o + pt.d * best_t;                   // r.at(x)
+    const v3 normal = unit(point - c);                       // sphere.rs:127
+    const DevMat mat = sc.mat[best];
+    const v3 cm = SPEC == 1 ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
+    MatP m; m.metallicness = mat.metallicness; m.opacity = mat.opacity; m.ir = mat.ir;
+    return shade_surface<SPEC>(A, pt, point, normal, cm, m, ld3(mat.emitted));
+}
+
 template <bool MOVING, int SPEC>
 __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float best_t) {
     if (best < 0) { shade_miss<SPEC>(A, pt); return true; }
     return shade_hit<MOVING, SPEC>(A, pt, best, best_t);
+}
+
+// Scenes with quads / instances (generic build only): finish Scene::collision_normal (viewport.rs:136-150) for
+// the query whose sphere part returned (best, best_t), then shade whichever object won.
+template <bool MOVING>
+__device__ __forceinline__ bool shade_geom(const KArgs &A, Path &pt, int best, float best_t, uint32_t &n_sph, uint32_t &n_quad) {
+    GeomHit h;
+    if (geom_closest(A.sc, A.geom, pt.o, pt.d, pt.tm, A.mint, A.maxt, best >= 0, best_t, pt.rng, h, n_sph, n_quad))
+        return shade_surface<0>(A, pt, h.point, h.normal, h.cm, h.m, h.emitted);
+    return shade<MOVING, 0>(A, pt, best, best_t);
 }
 
 // A path ended: bank its radiance in the sample buffer (the resolve kernel adds the samples of a pixel
@@ -259,6 +276,12 @@ __device__ __forceinline__ void flush_counters(const KArgs &A, uint32_t n_seg, u
     }
 }
 
+__device__ __forceinline__ void flush_quads(const KArgs &A, uint32_t n_quad) {
+    unsigned long long q = n_quad;
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&A.stats[14], q);
+}
+
 // ================================================================================================
 // brute force: closest hit in list order (camera_tests.rs:19-33; `min_hit == None || min_hit > i`)
 // ================================================================================================
@@ -306,13 +329,13 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
     for (; s < n; ++s) test(geom[s], MOVING ? vel[s] : zero, s);
 }
 
-template <bool MOVING, int SPEC>
+template <bool MOVING, int SPEC, bool GEOM>
 __global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
     Reserve rs; rs.next = rs.end = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
-    uint32_t n_seg = 0, n_rays = 0;
+    uint32_t n_seg = 0, n_rays = 0, n_isph = 0, n_quad = 0;
 
     for (;;) {
         if (fetch_pixel(A, !have && !dead, px, dead, rs)) { have = true; newpath = true; }
@@ -326,7 +349,7 @@ __global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
                 int best; float best_t;
                 closest_brute<MOVING>(A.sc, pt.o, pt.d, pt.tm, A.mint, A.maxt, best, best_t);
                 n_seg++;
-                finished = shade<MOVING, SPEC>(A, pt, best, best_t);
+                finished = GEOM ? shade_geom<MOVING>(A, pt, best, best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, best, best_t);
             }
             if (finished) {
                 if (finish_path(A, px, pt)) have = false;
@@ -334,7 +357,8 @@ __global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
             }
         }
     }
-    flush_counters(A, n_seg, n_rays, (unsigned long long)n_seg * A.sc.n, 0);
+    flush_counters(A, n_seg, n_rays, (unsigned long long)n_seg * A.sc.n + n_isph, 0);
+    if (GEOM) flush_quads(A, n_quad);
 }
 
 // ================================================================================================
@@ -536,8 +560,8 @@ __device__ __forceinline__ int trav_node(const DevBvh &bv, Trav &tr, int *stack)
 #ifndef RTW_BVH_WAVES
 #define RTW_BVH_WAVES 4        /* min waves per SIMD the register allocator must leave room for */
 #endif
-template <bool MOVING, bool LDSN, int SPEC>
-__global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KArgs A) {
+template <bool MOVING, bool LDSN, int SPEC, bool GEOM>
+__global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bvh(const KArgs A) {
     // LDS is all dynamic, sized by the host for THIS tree (rtw_ctx_render): the per-lane traversal stack
     // [level][thread] (a level is one conflict-free row; depth + 1 levels, 16-bit entries in the LDS-node
     // variant), then -- LDS-node variant -- the f16 nodes and, when it does not cost a resident workgroup,
@@ -563,7 +587,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
     Trav tr; tr.node = 0; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
-    uint32_t n_seg = 0, n_rays = 0, n_nodes = 0, n_tests = 0;
+    uint32_t n_seg = 0, n_rays = 0, n_nodes = 0, n_tests = 0, n_quad = 0;
     bool path_done = false;                         // a finished path waits for the next SHADE step to bank it
     uint32_t c_steps[3] = { 0, 0, 0 };              // wave-uniform (SGPR) census of the scheduler
     unsigned long long c_lanes[3] = { 0, 0, 0 };
@@ -594,7 +618,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
                 if (inflight) {
                     inflight = false;
                     n_seg++;
-                    path_done = shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t);
+                    path_done = GEOM ? shade_geom<MOVING>(A, pt, tr.best, tr.best_t, n_tests, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t);
                 }
                 if (path_done) { path_done = false; if (finish_path(A, px, pt)) have = false; else newpath = true; }
                 need_unit = !have;
@@ -647,6 +671,7 @@ __global__ __launch_bounds__(RTW_BLOCK, RTW_BVH_WAVES) void render_bvh(const KAr
 #endif
     }
     flush_counters(A, n_seg, n_rays, n_tests, n_nodes);
+    if (GEOM) flush_quads(A, n_quad);
     if ((threadIdx.x & 63u) == 0) {
         for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[5 + k], (unsigned long long)c_steps[k]); atomicAdd(&A.stats[8 + k], c_lanes[k]); }
 #ifdef RTW_STAMP
@@ -665,12 +690,21 @@ static bool is_common_config(const KArgs &a) {
 template <int SPEC>
 static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, bool lds_nodes) {
     if (accel == RTW_ACCEL_BVH) {
-        if (lds_nodes) return moving ? render_bvh<true, true, SPEC> : render_bvh<false, true, SPEC>;
-        return moving ? render_bvh<true, false, SPEC> : render_bvh<false, false, SPEC>;
+        if (lds_nodes) return moving ? render_bvh<true, true, SPEC, false> : render_bvh<false, true, SPEC, false>;
+        return moving ? render_bvh<true, false, SPEC, false> : render_bvh<false, false, SPEC, false>;
     }
-    return moving ? render_brute<true, SPEC> : render_brute<false, SPEC>;
+    return moving ? render_brute<true, SPEC, false> : render_brute<false, SPEC, false>;
+}
+// quads / instances in the scene: the generic build with the extra closest-hit stage
+static kernel_fn pick_kernel_geom(bool moving, uint32_t accel, bool lds_nodes) {
+    if (accel == RTW_ACCEL_BVH) {
+        if (lds_nodes) return moving ? render_bvh<true, true, 0, true> : render_bvh<false, true, 0, true>;
+        return moving ? render_bvh<true, false, 0, true> : render_bvh<false, false, 0, true>;
+    }
+    return moving ? render_brute<true, 0, true> : render_brute<false, 0, true>;
 }
 static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes) {
+    if (a.geom.n_quads || a.geom.n_inst) return pick_kernel_geom(moving, accel, lds_nodes);
     if (!is_common_config(a)) return pick_kernel_spec<0>(moving, accel, lds_nodes);
     return a.has_textures ? pick_kernel_spec<2>(moving, accel, lds_nodes) : pick_kernel_spec<1>(moving, accel, lds_nodes);
 }

@@ -33,6 +33,8 @@ struct rtw_ctx {
     DevScene sc{};
     float bg[3] = { 0, 0, 0 };
     void *d_geom = nullptr, *d_vel = nullptr, *d_mat = nullptr, *d_tex = nullptr, *d_texels = nullptr;
+    DevGeom geom{};
+    void *d_quads = nullptr, *d_inst = nullptr, *d_igeom = nullptr, *d_ivel = nullptr, *d_imat = nullptr, *d_iquads = nullptr;
     DevBvh bvh{};
     void *d_nodes = nullptr, *d_nodes16 = nullptr, *d_big_geom = nullptr, *d_big_vel = nullptr, *d_big_index = nullptr;
     // scratch
@@ -43,6 +45,48 @@ struct rtw_ctx {
     float *d_samples = nullptr;          // per-sample radiance bank (see rtw_ctx_render)
     size_t d_samples_cap = 0;
 };
+
+// The device records of a sphere list (sphere.rs:13-20 + materials.rs:15-20)
+static void prepare_spheres(const RtwSphere *sp, uint32_t n, std::vector<f4> &geom, std::vector<f4> &vel, std::vector<DevMat> &mat, bool &moving) {
+    geom.resize(n); vel.resize(n); mat.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const RtwSphere &s = sp[i];
+        geom[i] = f4{ s.center[0], s.center[1], s.center[2], host_mul(s.radius, s.radius) };   // sphere.rs:105 radius*radius
+        vel[i] = f4{ s.velocity[0], s.velocity[1], s.velocity[2], 0.0f };
+        if (s.velocity[0] != 0.0f || s.velocity[1] != 0.0f || s.velocity[2] != 0.0f) moving = true;
+        DevMat &m = mat[i];
+        std::memset(&m, 0, sizeof m);
+        for (int k = 0; k < 3; k++) {
+            // tex < 0: (texel * 1.0) * col_mod hoisted (texture.rs:265, sphere.rs:145)
+            m.cm[k] = s.tex < 0 ? host_mul(host_mul(s.tex_color[k], 1.0f), s.col_mod[k]) : s.col_mod[k];
+            m.emitted[k] = s.emitted[k];
+        }
+        m.metallicness = s.metallicness; m.opacity = s.opacity; m.ir = s.ir; m.tex = s.tex;
+    }
+}
+
+// Quad::new (quad.rs:84-110): n = u x v, normal = unit(n), d = normal . origin, w = n / (n . n) -- one rounding per
+// written operation (this TU is built with -ffp-contract=off), the oracle computes the same independently.
+static void prepare_quads(const RtwQuad *q, uint32_t n, std::vector<DevQuad> &out) {
+    out.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const RtwQuad &s = q[i];
+        DevQuad &d = out[i];
+        std::memset(&d, 0, sizeof d);
+        const float nx = s.u[1] * s.v[2] - s.u[2] * s.v[1], ny = s.u[2] * s.v[0] - s.u[0] * s.v[2], nz = s.u[0] * s.v[1] - s.u[1] * s.v[0];
+        const float len = std::sqrt(nx * nx + ny * ny + nz * nz);
+        d.normal[0] = nx / len; d.normal[1] = ny / len; d.normal[2] = nz / len;
+        d.d = d.normal[0] * s.origin[0] + d.normal[1] * s.origin[1] + d.normal[2] * s.origin[2];
+        const float nn = nx * nx + ny * ny + nz * nz;
+        d.w[0] = nx / nn; d.w[1] = ny / nn; d.w[2] = nz / nn;
+        for (int k = 0; k < 3; k++) {
+            d.origin[k] = s.origin[k]; d.u[k] = s.u[k]; d.v[k] = s.v[k];
+            d.albedo[k] = host_mul(s.tex_color[k], 1.0f);            // texture.rs:265
+            d.emitted[k] = s.emitted[k];
+        }
+        d.metallicness = s.metallicness; d.opacity = s.opacity; d.ir = s.ir; d.tex = s.tex;
+    }
+}
 
 template <class T>
 static int upload(void **dst, const std::vector<T> &src) {
@@ -101,7 +145,8 @@ int rtw_ctx_create(int device, rtw_ctx **out) {
 }
 
 static void free_scene(rtw_ctx *c) {
-    void **bufs[] = { &c->d_geom, &c->d_vel, &c->d_mat, &c->d_tex, &c->d_texels, &c->d_nodes, &c->d_nodes16, &c->d_big_geom, &c->d_big_vel, &c->d_big_index };
+    void **bufs[] = { &c->d_quads, &c->d_inst, &c->d_igeom, &c->d_ivel, &c->d_imat, &c->d_iquads,
+                      &c->d_geom, &c->d_vel, &c->d_mat, &c->d_tex, &c->d_texels, &c->d_nodes, &c->d_nodes16, &c->d_big_geom, &c->d_big_vel, &c->d_big_index };
     for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
     c->has_scene = false;
 }
@@ -129,8 +174,22 @@ int rtw_ctx_set_stream(rtw_ctx *c, void *hip_stream) {
 int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end) {
     if (!c || !s || (s->n_spheres && !s->spheres)) return RTW_E_INVALID;
     if ((s->n_textures && !s->textures) || (s->n_texels && !s->texels)) return RTW_E_INVALID;
+    if ((s->n_quads && !s->quads) || (s->n_instances && !s->instances)) return RTW_E_INVALID;
+    if ((s->n_inst_spheres && !s->inst_spheres) || (s->n_inst_quads && !s->inst_quads)) return RTW_E_INVALID;
     for (uint32_t i = 0; i < s->n_spheres; i++)
         if (s->spheres[i].tex >= (int32_t)s->n_textures) return RTW_E_INVALID;
+    for (uint32_t i = 0; i < s->n_inst_spheres; i++)
+        if (s->inst_spheres[i].tex >= (int32_t)s->n_textures) return RTW_E_INVALID;
+    for (uint32_t i = 0; i < s->n_quads; i++)
+        if (s->quads[i].tex >= (int32_t)s->n_textures) return RTW_E_INVALID;
+    for (uint32_t i = 0; i < s->n_inst_quads; i++)
+        if (s->inst_quads[i].tex >= (int32_t)s->n_textures) return RTW_E_INVALID;
+    for (uint32_t i = 0; i < s->n_instances; i++) {
+        const RtwInstance &in = s->instances[i];
+        if ((uint64_t)in.first_sphere + in.n_spheres > s->n_inst_spheres) return RTW_E_INVALID;
+        if ((uint64_t)in.first_quad + in.n_quads > s->n_inst_quads) return RTW_E_INVALID;
+        if (in.medium > RTW_MEDIUM_CONST_DENSITY) return RTW_E_INVALID;
+    }
     for (uint32_t i = 0; i < s->n_textures; i++) {
         const RtwTexture &t = s->textures[i];
         if (t.row == 0 || t.col == 0 || (uint64_t)t.texel_offset + (uint64_t)t.row * t.col > s->n_texels) return RTW_E_INVALID;
@@ -138,29 +197,46 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     HIP_TRY(hipSetDevice(c->device));
     free_scene(c);
 
-    std::vector<f4> geom(s->n_spheres), vel(s->n_spheres);
-    std::vector<DevMat> mat(s->n_spheres);
+    std::vector<f4> geom, vel;
+    std::vector<DevMat> mat;
     bool moving = false;
-    for (uint32_t i = 0; i < s->n_spheres; i++) {
-        const RtwSphere &sp = s->spheres[i];
-        geom[i] = f4{ sp.center[0], sp.center[1], sp.center[2], host_mul(sp.radius, sp.radius) };   // sphere.rs:105 radius*radius
-        vel[i] = f4{ sp.velocity[0], sp.velocity[1], sp.velocity[2], 0.0f };
-        if (sp.velocity[0] != 0.0f || sp.velocity[1] != 0.0f || sp.velocity[2] != 0.0f) moving = true;
-        DevMat &m = mat[i];
-        std::memset(&m, 0, sizeof m);
-        for (int k = 0; k < 3; k++) {
-            // tex < 0: (texel * 1.0) * col_mod hoisted (texture.rs:265, sphere.rs:145)
-            m.cm[k] = sp.tex < 0 ? host_mul(host_mul(sp.tex_color[k], 1.0f), sp.col_mod[k]) : sp.col_mod[k];
-            m.emitted[k] = sp.emitted[k];
-        }
-        m.metallicness = sp.metallicness; m.opacity = sp.opacity; m.ir = sp.ir; m.tex = sp.tex;
-    }
+    prepare_spheres(s->spheres, s->n_spheres, geom, vel, mat, moving);
     std::vector<RtwTexture> tex(s->textures, s->textures + s->n_textures);
     std::vector<float> texels(s->texels, s->texels + 3 * (size_t)s->n_texels);
 
     int rc;
     if ((rc = upload(&c->d_geom, geom)) || (rc = upload(&c->d_vel, vel)) || (rc = upload(&c->d_mat, mat)) ||
         (rc = upload(&c->d_tex, tex)) || (rc = upload(&c->d_texels, texels))) { free_scene(c); return rc; }
+
+    // quads and instances (Scene::new, viewport.rs:122-135).  Their AABB trees (qaabb.rs, iaabb.rs) only prune list
+    // walks over a handful of objects: the device walks the lists.
+    {
+        std::vector<DevQuad> quads, iquads;
+        std::vector<f4> igeom, ivel; std::vector<DevMat> imat;
+        std::vector<DevInstance> inst(s->n_instances);
+        bool imoving = false;
+        prepare_quads(s->quads, s->n_quads, quads);
+        prepare_quads(s->inst_quads, s->n_inst_quads, iquads);
+        prepare_spheres(s->inst_spheres, s->n_inst_spheres, igeom, ivel, imat, imoving);
+        for (uint32_t i = 0; i < s->n_instances; i++) {
+            const RtwInstance &in = s->instances[i];
+            DevInstance &d = inst[i];
+            std::memset(&d, 0, sizeof d);
+            d.first_sphere = in.first_sphere; d.n_spheres = in.n_spheres; d.first_quad = in.first_quad; d.n_quads = in.n_quads;
+            d.density = in.density; d.medium = in.medium;
+            for (int k = 0; k < 3; k++) {
+                d.tr[k] = in.translation[k];
+                d.back[2 * k] = std::sin(-in.rotation[k]); d.back[2 * k + 1] = std::cos(-in.rotation[k]);   // rotated(-self.rotation) (instance.rs:258)
+                d.fwd[2 * k] = std::sin(in.rotation[k]);   d.fwd[2 * k + 1] = std::cos(in.rotation[k]);     // vec3.rs:163-170
+            }
+        }
+        if ((rc = upload(&c->d_quads, quads)) || (rc = upload(&c->d_iquads, iquads)) || (rc = upload(&c->d_inst, inst)) ||
+            (rc = upload(&c->d_igeom, igeom)) || (rc = upload(&c->d_ivel, ivel)) || (rc = upload(&c->d_imat, imat))) { free_scene(c); return rc; }
+        c->geom.quads = (const DevQuad *)c->d_quads; c->geom.iquads = (const DevQuad *)c->d_iquads;
+        c->geom.inst = (const DevInstance *)c->d_inst;
+        c->geom.igeom = (const f4 *)c->d_igeom; c->geom.ivel = (const f4 *)c->d_ivel; c->geom.imat = (const DevMat *)c->d_imat;
+        c->geom.n_quads = s->n_quads; c->geom.n_inst = s->n_instances;
+    }
 
     // acceleration structure (Scene::new_sphere builds the AABB tree, viewport.rs:90-105)
     BvhBuild bb;
@@ -204,7 +280,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
 
     KArgs a;
     std::memset(&a, 0, sizeof a);
-    a.cam = *cam; a.sc = c->sc; a.bvh = c->bvh;
+    a.cam = *cam; a.sc = c->sc; a.bvh = c->bvh; a.geom = c->geom;
     if (p->flags & RTW_FLAG_GLOBAL_NODES) a.bvh.nodes16 = nullptr;
     a.width = p->width; a.height = p->height;
     const uint32_t n_rows = rtw_part_rows(p->height, p->row_block, p->part_index, p->part_count);
@@ -311,6 +387,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
         stats->camera_rays = h_stats[0]; stats->segments = h_stats[1];
         stats->sphere_tests = h_stats[2]; stats->node_tests = h_stats[3];
         stats->nan_pixels = (uint32_t)h_stats[4]; stats->rows = n_rows;
+        stats->quad_tests = h_stats[14];
         stats->kernel_ms = ms;
         for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
         if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu\n", h_stats[11], h_stats[12], h_stats[13]);

@@ -8,8 +8,11 @@ rows = []
 cfgs = [("C1 3 spheres", R.SCENE_C1, R.SCENE_C1, None), ("C2 Book-1 final", R.SCENE_C2, R.SCENE_C2, None),
         ("C3 Book-1 final (bench)", R.SCENE_C2, R.SCENE_C5, 0.0), ("C4 dielectric-heavy", R.SCENE_C4, R.SCENE_C4, None),
         ("C5 motion blur + texture", R.SCENE_C5, R.SCENE_C5, None)]
+cfgs += [("quad_test (quad.rs:152)", R.SCENE_QUAD_TEST, R.SCENE_QUAD_TEST, None), ("presentation_image (main.rs:89)", R.SCENE_PRESENTATION, R.SCENE_PRESENTATION, None),
+         ("First frame (main.rs:427)", R.SCENE_FIRST_FRAME, R.SCENE_FIRST_FRAME, None)]
 for name, scene_id, view_id, shutter in cfgs:
-    sc = R.Scene.generate(scene_id); cam, p = R.default_view(view_id)
+    sc = R.Scene.generate_geom(scene_id) if scene_id in (R.SCENE_QUAD_TEST, R.SCENE_PRESENTATION) else R.Scene.generate(scene_id)
+    cam, p = R.default_view(view_id)
     if shutter is not None: cam.shutter = shutter
     out = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device="cuda:0")
     r.set_scene(sc, cam.time0, cam.time0 + cam.shutter)
@@ -23,5 +26,5 @@ for name, scene_id, view_id, shutter in cfgs:
             if best is None or st.kernel_ms < best.kernel_ms: best = st
         res[accel] = best
     b, f = res[R.ACCEL_BVH], res[R.ACCEL_BRUTE]
-    print(f"| {name} | {sc.n_spheres} | {p.width}x{p.height}x{b.camera_rays // (p.width * p.height)} | {p.depth} | {b.segments / b.camera_rays:.2f} | "
+    print(f"| {name} | {sc.n_spheres}+{sc.n_quads}q+{sc.n_instances}i | {p.width}x{p.height}x{b.camera_rays // (p.width * p.height)} | {p.depth} | {b.segments / b.camera_rays:.2f} | "
           f"{b.kernel_ms:.2f} | {b.segments / b.kernel_ms / 1e6:.2f} | {b.camera_rays / b.kernel_ms / 1e6:.2f} | {f.kernel_ms:.2f} | {f.segments / f.kernel_ms / 1e6:.2f} |", flush=True)

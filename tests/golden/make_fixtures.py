@@ -10,6 +10,13 @@ committed so that the GPU box and later rounds never need the reference tree.
   ref_sphere_hits.json  Sphere::collisionNormal outputs of the reference's own objects (oracle/_ref)
                       for seeded random rays: t, normal, point, next direction (RNG-free materials only).
   ref_camera.json     the reference C++ Camera for four configurations.
+  ref_images.npz      two images the reference itself rendered and checked in, reduced to 16x16-block means of
+                      the 8-bit values (25x25x3 each) + the count of pure-black pixels:
+                        Rust/Presentation.png  presentation_image (Rust/src/main.rs:89-419): 2500 spp, quads,
+                                               a light, a smoke box, a glass pane, ray_color_bg_color
+                        Rust/First frame.png   main()'s seven spheres (main.rs:427-545): 100 spp, depth 100
+                      Both were rendered with the reference's unseeded ThreadRng, so they pin the restatement
+                      statistically (block means), not bit for bit.
 """
 import ctypes as C
 import hashlib
@@ -72,7 +79,23 @@ def parse_cerr():
     return pixels
 
 
+def ref_images():
+    from PIL import Image
+    out = {}
+    for key, rel in (("presentation", "Rust/Presentation.png"), ("first_frame", "Rust/First frame.png")):
+        img = np.asarray(Image.open(os.path.join(REF, rel)).convert("RGB")).astype(np.float64)
+        h, w, _ = img.shape
+        assert (h, w) == (400, 400)
+        out[key + "_blocks16"] = img.reshape(h // 16, 16, w // 16, 16, 3).mean(axis=(1, 3)).astype(np.float32)
+        out[key + "_black_pixels"] = np.array([(img.sum(axis=2) == 0).sum()])
+        print(rel, "black pixels", int(out[key + "_black_pixels"][0]), "mean", img.mean(axis=(0, 1)))
+    np.savez_compressed(os.path.join(HERE, "ref_images.npz"), **out)
+
+
 def main():
+    if sys.argv[1:] == ["images"]:
+        return ref_images()
+    ref_images()
     from tests import oracle_binding as O
     import rtw_amd as R
     assert O.have_ref(), "build oracle/_ref first (make -C oracle)"

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 17, names
     for n in names:
         assert hasattr(L, n), f"librtw_hip.so does not export {n}"
-    assert L.rtw_abi_version() == 1
+    assert L.rtw_abi_version() == 2
 
 
 def test_oracle_exports_every_declared_symbol():
@@ -40,8 +40,10 @@ def test_pod_sizes_match_header():
     assert C.sizeof(R.RtwSphere) == 80
     assert C.sizeof(R.RtwTexture) == 16
     assert C.sizeof(R.RtwParams) == 72
-    assert C.sizeof(R.RtwStats) == 96
-    assert C.sizeof(R.RtwScene) == 48
+    assert C.sizeof(R.RtwStats) == 104
+    assert C.sizeof(R.RtwScene) == 96
+    assert C.sizeof(R.RtwQuad) == 88
+    assert C.sizeof(R.RtwInstance) == 48
 
 
 def test_no_device_is_an_error_not_a_fallback():

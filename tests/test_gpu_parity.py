@@ -7,6 +7,7 @@ Textured spheres add atan2f/acosf (texel choice): a handful of pixels may pick a
 north_star's tolerance is per-channel |delta| < 1e-3; what is asserted here is far tighter.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -417,3 +418,88 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(gpu):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert abs(d["roofline"]["units_per_launch"]["segments"] * 2 / (1920 * 1080 * 8) - d["config"]["segments_per_camera_ray"]) < 1e-3
+
+
+# ---- quads, instances, constant-density medium -------------------------------------------
+def _blocks16(img):
+    q = np.round(np.clip(np.nan_to_num(img.astype(np.float64)) * 255.0, 0, 255))
+    h, w, _ = q.shape
+    return q.reshape(h // 16, 16, w // 16, 16, 3).mean(axis=(1, 3))
+
+
+def test_quad_test_scene_bit_exact(gpu):
+    # objects/quad.rs:152-299 at its own size: 400 x 400, 100 spp (stratified), depth 10
+    scene = R.Scene.generate_geom(R.SCENE_QUAD_TEST)
+    cam, p = R.default_view(R.SCENE_QUAD_TEST)
+    p.gamma = 1.0
+    ref, st_ref, out = render_both(gpu, scene, cam, p)
+    for accel, (img, st) in out.items():
+        assert st.segments == st_ref.segments and st.quad_tests == st_ref.quad_tests == 5 * st.segments
+        assert np.array_equal(img, ref), f"accel {accel}"
+
+
+def test_presentation_scene_bit_exact_and_matches_the_reference_png(gpu):
+    # presentation_image (main.rs:89-419): sphere + 6 quads (mirror, light, lambert) + smoke box + glass pane
+    scene = R.Scene.generate_geom(R.SCENE_PRESENTATION)
+    cam, p = R.default_view(R.SCENE_PRESENTATION)
+    p.gamma, p.samples = 1.0, 24
+    ref, st_ref, out = render_both(gpu, scene, cam, p)
+    for accel, (img, st) in out.items():
+        assert st.segments == st_ref.segments and st.quad_tests == st_ref.quad_tests and st.sphere_tests == st_ref.sphere_tests
+        assert st.nan_pixels == st_ref.nan_pixels
+        assert np.array_equal(img, ref, equal_nan=True), f"accel {accel}"
+    # the frame as the reference rendered it (400 x 400 x 2500 spp, gamma 2) against the reference's own PNG
+    cam, p = R.default_view(R.SCENE_PRESENTATION)
+    img, st = gpu.render(cam, p)
+    assert st.camera_rays == 400 * 400 * 2500
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_images.npz"))
+    d = _blocks16(img) - gold["presentation_blocks16"]
+    assert np.abs(d).mean() < 0.35 and np.abs(d).max() < 3.0 and np.abs(d.mean(axis=(0, 1))).max() < 0.15, (np.abs(d).mean(), np.abs(d).max())
+    assert 5 <= st.nan_pixels <= 80          # the reference's PNG has 27 such black pixels
+
+
+def test_first_frame_scene_bit_exact_and_matches_the_reference_png(gpu):
+    scene = R.Scene.generate(R.SCENE_FIRST_FRAME)
+    cam, p = R.default_view(R.SCENE_FIRST_FRAME)
+    p.gamma = 1.0
+    ref, st_ref, out = render_both(gpu, scene, cam, p)
+    for accel, (img, st) in out.items():
+        assert st.segments == st_ref.segments
+        assert np.array_equal(img, ref), f"accel {accel}"
+    cam, p = R.default_view(R.SCENE_FIRST_FRAME)
+    p.samples = 1600                            # 16x the reference's 100 spp: the comparison is limited by ITS noise
+    img, _ = gpu.render(cam, p)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_images.npz"))
+    d = _blocks16(img) - gold["first_frame_blocks16"]
+    assert np.abs(d).mean() < 0.3 and np.abs(d).max() < 3.0 and np.abs(d.mean(axis=(0, 1))).max() < 0.15, (np.abs(d).mean(), np.abs(d).max())
+
+
+def test_mixed_scene_instances_with_spheres_textures_motion(gpu):
+    # everything at once: top-level spheres (one moving, one image-textured) + quads (one image-textured, one light) +
+    # an instance holding spheres and quads under a 3-axis rotation + a smoke sphere-and-box instance
+    rng = np.random.default_rng(11)
+    tex = rng.uniform(0.1, 0.9, size=(3, 5, 3)).astype(np.float32)
+    spheres = [R.Sphere.new((0, -100.5, -1), 100.0, (0.8, 0.8, 0.0), R.SCATTER_M),
+               R.Sphere.new_moving((-1.2, 0.0, -1.5), 0.4, (0.9, 0.4, 0.4), R.FUZZY3_M, (0.0, 3.0, 0.0)),
+               R.Sphere.new_with_texture((1.3, 0.1, -1.8), 0.5, None, R.SCATTER_M, 0)]
+    quads = [R.Quad.new((-3, -0.5, -4), (6, 0, 0), (0, 3, 0), R.SCATTER_M, (1, 1, 1), tex_index=0),
+             R.Quad.new((-0.5, 2.0, -2.5), (1, 0, 0), (0, 0, 1), (0.0, 0.0, 1.0), (1, 1, 1), emitted=(6, 5, 4))]
+    a = R.Instance.new([R.Sphere.new((0.0, 0.0, 0.0), 0.3, (0.5, 0.7, 0.9), R.GLASS_M), R.Sphere.new((0.5, 0.2, 0.1), 0.2, (0.9, 0.9, 0.9), R.METALLIC_M)],
+                       [R.Quad.new((-0.6, -0.4, 0.4), (1.2, 0, 0), (0, 0.8, 0), R.METALLIC_M, (0.8, 0.8, 0.8))])
+    a.rotate((0.3, -0.7, 1.1)); a.translate((0.2, 0.3, -1.2))
+    b = R.Instance.new_box((-0.4, -0.3, -0.3), (0.4, 0.3, 0.3), (0.3, 0.3, 0.3), R.SCATTER_M)
+    b.spheres.append(R.Sphere.new((0.0, 0.5, 0.0), 0.25, (0.6, 0.6, 0.6), R.SCATTER_M).pod)
+    b.rotate((0.0, 0.6, 0.0)); b.translate((-0.4, 0.0, -0.9)); b.const_density(3.0)
+    scene = R.Scene(spheres, textures=[tex], background=(0.05, 0.06, 0.1), quads=quads, instances=[a, b])
+    vp = R.Viewport.new_from_res(160, 96, 16, 12, 1.0, vfov=70.0, lens_radius=0.02)
+    vp.shutter_speed, vp.fps = 1.0 / 30.0, 30.0
+    cam = vp.camera()
+    for integrator in (R.INTEGRATOR_BG_COLOR, R.INTEGRATOR_GRADIENT, R.INTEGRATOR_RUST2, R.INTEGRATOR_NORMAL):
+        p = vp.params(integrator, R.SAMPLER_ROW)
+        ref, st_ref, out = render_both(gpu, scene, cam, p)
+        for accel, (img, st) in out.items():
+            assert st.segments == st_ref.segments and st.quad_tests == st_ref.quad_tests, (integrator, accel)
+            same = np.isclose(img, ref, rtol=0, atol=0, equal_nan=True).all(axis=2)
+            # sphere / quad image textures go through atan2f / acosf / floorf of a product: a texel edge may fall differently
+            assert same.mean() > 0.999, (integrator, accel, same.mean())
+            assert np.nanmax(np.abs(np.where(np.isnan(ref), 0, img - ref))) < 1.0
