@@ -14,9 +14,21 @@ pub struct RtwSphere { pub center: [f32; 3], pub radius: f32, pub velocity: [f32
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RtwTexture { pub row: u32, pub col: u32, pub texel_offset: u32, pub reserved: u32 }
 
+/// `Quad` (objects/quad.rs:8-20) + its Material; normal / d / w of Quad::new are recomputed by the library.
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RtwQuad { pub origin: [f32; 3], pub u: [f32; 3], pub v: [f32; 3], pub velocity: [f32; 3], pub tex_color: [f32; 3],
+    pub metallicness: f32, pub opacity: f32, pub ir: f32, pub emitted: [f32; 3], pub tex: i32 }
+
+/// `Instance` (objects/instance.rs:27-38): member ranges into the scene's instance pools; medium 1 = const_density.
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RtwInstance { pub first_sphere: u32, pub n_spheres: u32, pub first_quad: u32, pub n_quads: u32,
+    pub translation: [f32; 3], pub rotation: [f32; 3], pub density: f32, pub medium: u32 }
+
 #[repr(C)]
 pub struct RtwScene { pub spheres: *const RtwSphere, pub textures: *const RtwTexture, pub texels: *const f32,
-    pub n_spheres: u32, pub n_textures: u32, pub n_texels: u32, pub background: [f32; 3] }
+    pub n_spheres: u32, pub n_textures: u32, pub n_texels: u32, pub background: [f32; 3],
+    pub quads: *const RtwQuad, pub instances: *const RtwInstance, pub inst_spheres: *const RtwSphere, pub inst_quads: *const RtwQuad,
+    pub n_quads: u32, pub n_instances: u32, pub n_inst_spheres: u32, pub n_inst_quads: u32 }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RtwParams { pub width: u32, pub height: u32, pub samples: u32, pub depth: u32, pub gamma: f32,
@@ -26,7 +38,7 @@ pub struct RtwParams { pub width: u32, pub height: u32, pub samples: u32, pub de
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]
 pub struct RtwStats { pub camera_rays: u64, pub segments: u64, pub sphere_tests: u64, pub node_tests: u64,
     pub nan_pixels: u32, pub rows: u32, pub kernel_ms: f32, pub total_ms: f32,
-    pub phase_steps: [u64; 3], pub phase_lanes: [u64; 3] }
+    pub phase_steps: [u64; 3], pub phase_lanes: [u64; 3], pub quad_tests: u64 }
 
 #[repr(C)] pub struct RtwCtx { _private: [u8; 0] }
 
@@ -66,7 +78,21 @@ impl Renderer {
     pub fn set_scene(&mut self, spheres: &[RtwSphere], textures: &[RtwTexture], texels: &[[f32; 3]],
                      background: [f32; 3], t_begin: f32, t_end: f32) -> Result<(), RtwError> {
         let sc = RtwScene { spheres: spheres.as_ptr(), textures: textures.as_ptr(), texels: texels.as_ptr() as *const f32,
-            n_spheres: spheres.len() as u32, n_textures: textures.len() as u32, n_texels: texels.len() as u32, background };
+            n_spheres: spheres.len() as u32, n_textures: textures.len() as u32, n_texels: texels.len() as u32, background,
+            quads: std::ptr::null(), instances: std::ptr::null(), inst_spheres: std::ptr::null(), inst_quads: std::ptr::null(),
+            n_quads: 0, n_instances: 0, n_inst_spheres: 0, n_inst_quads: 0 };
+        check(unsafe { rtw_ctx_set_scene(self.ctx, &sc, t_begin, t_end) })
+    }
+    /// == Scene::new(spheres, quads, instances) (viewport.rs:122-135).  `inst_spheres` / `inst_quads` are the member pools
+    /// the instances' ranges index (Instance{spheres, quads} flattened in instance order).
+    pub fn set_scene_full(&mut self, spheres: &[RtwSphere], quads: &[RtwQuad], instances: &[RtwInstance],
+                          inst_spheres: &[RtwSphere], inst_quads: &[RtwQuad], textures: &[RtwTexture], texels: &[[f32; 3]],
+                          background: [f32; 3], t_begin: f32, t_end: f32) -> Result<(), RtwError> {
+        let sc = RtwScene { spheres: spheres.as_ptr(), textures: textures.as_ptr(), texels: texels.as_ptr() as *const f32,
+            n_spheres: spheres.len() as u32, n_textures: textures.len() as u32, n_texels: texels.len() as u32, background,
+            quads: quads.as_ptr(), instances: instances.as_ptr(), inst_spheres: inst_spheres.as_ptr(), inst_quads: inst_quads.as_ptr(),
+            n_quads: quads.len() as u32, n_instances: instances.len() as u32,
+            n_inst_spheres: inst_spheres.len() as u32, n_inst_quads: inst_quads.len() as u32 };
         check(unsafe { rtw_ctx_set_scene(self.ctx, &sc, t_begin, t_end) })
     }
     /// -> `Img`-shaped rows ([height][width] of Rgb<f32>), gamma-corrected, unclamped (viewport.rs:301).

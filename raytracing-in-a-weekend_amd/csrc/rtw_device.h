@@ -309,7 +309,10 @@ __device__ __forceinline__ void quad_test(const DevScene &sc, const DevQuad *qua
     if (alfa < 0.0f || alfa > 1.0f || beta < 0.0f || beta > 1.0f) return;
     if (found && !(h.t > t)) return;
     const f4 r5 = q[5], r6 = q[6];
-    const int32_t tex = __builtin_bit_cast(int32_t, r4.w);
+    // (a scalar copy first: __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 with this
+    //  toolchain -- seen in the ISA as the texture id compared against w.x)
+    const float tex_bits = r4.w;
+    const int32_t tex = __float_as_int(tex_bits);
     v3 cm = mk(r5.x, r5.y, r5.z);
     if (tex >= 0) {                                            // quad.rs:64-79
         const RtwTexture tx = sc.tex[tex];
