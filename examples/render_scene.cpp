@@ -3,6 +3,7 @@
 // against the C ABI of include/rtw.h only.  Compiled by `make -C raytracing-in-a-weekend_amd/csrc example`.
 //
 //   render_scene --scene metal --out metal_test.png
+//   render_scene --scene presentation --out Presentation.png      (presentation_image, Rust/src/main.rs:89-419)
 //   render_scene --json scene.json --width 400 --height 225 --spp 100 --depth 10 --out scene.png
 #include "rtw.h"
 
@@ -35,7 +36,9 @@ int main(int argc, char **argv) {
     }
     uint32_t which = scene_name == "c1" ? RTW_SCENE_C1_THREE_SPHERES : scene_name == "book1" ? RTW_SCENE_C2_BOOK1_FINAL
                    : scene_name == "dielectric" ? RTW_SCENE_C4_DIELECTRIC : scene_name == "motion" ? RTW_SCENE_C5_MOTION_CHECKER
-                   : RTW_SCENE_METAL_TEST;
+                   : scene_name == "presentation" ? RTW_SCENE_PRESENTATION : scene_name == "quads" ? RTW_SCENE_QUAD_TEST
+                   : scene_name == "firstframe" ? RTW_SCENE_FIRST_FRAME : RTW_SCENE_METAL_TEST;
+    const bool geom = which == RTW_SCENE_PRESENTATION || which == RTW_SCENE_QUAD_TEST;
 
     std::vector<RtwSphere> spheres; std::vector<RtwTexture> textures; std::vector<float> texels;
     uint32_t ns = 0, nt = 0, nx = 0;
@@ -49,12 +52,26 @@ int main(int argc, char **argv) {
         if ((rc = rtw_scene_from_json(text.data(), text.size(), nullptr, 0, &ns, nullptr, 0, &nt, nullptr, 0, &nx))) return die("scene json", rc);
         spheres.resize(ns ? ns : 1); textures.resize(nt ? nt : 1); texels.resize(3 * (nx ? nx : 1));
         if ((rc = rtw_scene_from_json(text.data(), text.size(), spheres.data(), ns, &ns, textures.data(), nt, &nt, texels.data(), nx, &nx))) return die("scene json", rc);
-    } else {
+    } else if (!geom) {
         if ((rc = rtw_scene_generate(which, 42, nullptr, 0, &ns, nullptr, 0, &nt, nullptr, 0, &nx))) return die("scene", rc);
         spheres.resize(ns ? ns : 1); textures.resize(nt ? nt : 1); texels.resize(3 * (nx ? nx : 1));
         if ((rc = rtw_scene_generate(which, 42, spheres.data(), ns, &ns, textures.data(), nt, &nt, texels.data(), nx, &nx))) return die("scene", rc);
     }
     RtwScene scene{ spheres.data(), textures.data(), texels.data(), ns, nt, nx, { 0, 0, 0 } };
+    std::vector<RtwQuad> quads, inst_quads; std::vector<RtwInstance> instances; std::vector<RtwSphere> inst_spheres;
+    if (geom && json_path.empty()) {                // Scene::new(spheres, quads, instances) (Rust/src/viewport.rs:122-135)
+        uint32_t n5[5] = { 0, 0, 0, 0, 0 };
+        if ((rc = rtw_scene_generate_geom(which, 42, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n5, scene.background))) return die("scene", rc);
+        spheres.resize(n5[0] ? n5[0] : 1); quads.resize(n5[1] ? n5[1] : 1); instances.resize(n5[2] ? n5[2] : 1);
+        inst_spheres.resize(n5[3] ? n5[3] : 1); inst_quads.resize(n5[4] ? n5[4] : 1);
+        if ((rc = rtw_scene_generate_geom(which, 42, spheres.data(), quads.data(), instances.data(), inst_spheres.data(), inst_quads.data(), n5, n5, scene.background))) return die("scene", rc);
+        ns = n5[0];
+        scene.spheres = spheres.data(); scene.n_spheres = n5[0];
+        scene.quads = quads.data(); scene.n_quads = n5[1];
+        scene.instances = instances.data(); scene.n_instances = n5[2];
+        scene.inst_spheres = inst_spheres.data(); scene.n_inst_spheres = n5[3];
+        scene.inst_quads = inst_quads.data(); scene.n_inst_quads = n5[4];
+    }
     if (!dump_json.empty()) {                       // Into<JsonValue> for Scene
         size_t n = rtw_scene_to_json(&scene, nullptr, 0);
         std::string text(n + 1, '\0');
@@ -67,7 +84,8 @@ int main(int argc, char **argv) {
     if ((rc = rtw_scene_default_view(which, &cam, &p))) return die("view", rc);
     if (width && height) {                          // Viewport::new_from_res(width, height, ..) keeping the view's origin/direction
         // the default views of the generators use the reference's default camera except for the Book-1 framing
-        const bool book1 = which != RTW_SCENE_C1_THREE_SPHERES && which != RTW_SCENE_METAL_TEST;
+        const bool book1 = which == RTW_SCENE_C2_BOOK1_FINAL || which == RTW_SCENE_C4_DIELECTRIC || which == RTW_SCENE_C5_MOTION_CHECKER;
+        if (geom) { std::fprintf(stderr, "--width/--height: the quad scenes keep their own view\n"); return 2; }
         const float from[3] = { 13, 2, 3 }, len = 13.4907375f, dir[3] = { -13 / len, -2 / len, -3 / len }, vfov = 20, lens = 0.05f;
         uint32_t h = 0;
         const float keep_time0 = cam.time0, keep_shutter = cam.shutter;
@@ -84,8 +102,8 @@ int main(int argc, char **argv) {
     std::vector<float> img((size_t)3 * p.width * p.height);
     RtwStats st;
     if ((rc = rtw_render(&cam, &scene, &p, img.data(), &st))) return die("rtw_render", rc);
-    std::printf("%u spheres, %ux%u, %llu camera rays, %llu segments, %.3f ms on the GPU (%.2f Gsegments/s), %u NaN pixels\n",
-                ns, p.width, p.height, (unsigned long long)st.camera_rays, (unsigned long long)st.segments, st.kernel_ms,
+    std::printf("%u spheres + %u quads + %u instances, %ux%u, %llu camera rays, %llu segments, %.3f ms on the GPU (%.2f Gsegments/s), %u NaN pixels\n",
+                ns, scene.n_quads, scene.n_instances, p.width, p.height, (unsigned long long)st.camera_rays, (unsigned long long)st.segments, st.kernel_ms,
                 st.segments / (st.kernel_ms * 1e6), st.nan_pixels);
     const bool ppm = out.size() > 4 && out.substr(out.size() - 4) == ".ppm";
     rc = ppm ? rtw_write_ppm_f32(out.c_str(), img.data(), p.width, p.height) : rtw_write_png_f32(out.c_str(), img.data(), p.width, p.height);

@@ -380,7 +380,7 @@ def test_example_program_through_the_c_abi(gpu, tmp_path):
         subprocess.run(["make", "-C", os.path.join(root, "raytracing-in-a-weekend_amd", "csrc"), "example"], check=True, capture_output=True)
     png, js = str(tmp_path / "m.png"), str(tmp_path / "m.json")
     out = subprocess.run([exe, "--scene", "metal", "--out", png, "--dump-json", js], check=True, capture_output=True, text=True).stdout
-    assert "4 spheres, 400x225, 9000000 camera rays" in out
+    assert "4 spheres + 0 quads + 0 instances, 400x225, 9000000 camera rays" in out
     scene = R.Scene.generate(R.SCENE_METAL_TEST)
     cam, p = R.default_view(R.SCENE_METAL_TEST)
     gpu.set_scene(scene)
@@ -401,6 +401,15 @@ def test_example_program_through_the_c_abi(gpu, tmp_path):
     subprocess.run([exe, "--json", js, "--width", "400", "--height", "225", "--spp", "100", "--depth", "10", "--out", png2], check=True, capture_output=True)
     # the JSON scene renders with the default view's ROW sampler at maxt 1e5 unless told otherwise: same scene, so only sanity here
     assert read_png(png2).shape == (225, 400, 3)
+    # presentation_image through the C ABI alone (Scene::new with quads and instances), reduced spp
+    png3 = str(tmp_path / "p.png")
+    out = subprocess.run([exe, "--scene", "presentation", "--spp", "64", "--out", png3], check=True, capture_output=True, text=True).stdout
+    assert "1 spheres + 6 quads + 2 instances, 400x400, 10240000 camera rays" in out
+    scene = R.Scene.generate_geom(R.SCENE_PRESENTATION)
+    cam, p = R.default_view(R.SCENE_PRESENTATION)
+    p.samples = 64
+    gpu.set_scene(scene)
+    assert np.array_equal(read_png(png3), R.quantize_u8(gpu.render(cam, p)[0]))
 
 
 def test_bench_two_ranks_rehearsal_on_one_gpu(gpu):
