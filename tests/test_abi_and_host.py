@@ -245,3 +245,56 @@ def test_bvh_builder_invariants():
             assert h == 0 and n + b + 1 == 900  # more than 512 nodes: no LDS copy
         if name in ("one", "none"):
             assert n == 0
+
+
+# ---- quads / instances: host constructors and generators (no GPU) ---------------------------------------
+def test_quad_and_box_constructors():
+    q = R.Quad.new((1, 2, 3), (4, 0, 0), (0, 5, 0), R.METALLIC_M, (0.1, 0.2, 0.3), emitted=(7, 8, 9)).pod
+    assert list(q.origin) == [1, 2, 3] and list(q.u) == [4, 0, 0] and list(q.v) == [0, 5, 0]
+    assert (q.metallicness, q.opacity, q.ir, q.tex) == (1.0, 0.0, 1.0, -1)
+    assert np.allclose(list(q.tex_color), [0.1, 0.2, 0.3]) and list(q.emitted) == [7, 8, 9] and list(q.velocity) == [0, 0, 0]
+    # Instance::new_box (instance.rs:83-176): front, right, back, left, top, bottom -- origins and edge vectors as written there
+    box = R.Instance.new_box((1.0, 0.5, 0.5), (-1.0, -0.5, -0.5), (0.2, 0.2, 0.2), R.SCATTER_M)     # corners in any order (minf/maxf)
+    want = [((-1, -.5, .5), (2, 0, 0), (0, 1, 0)), ((1, -.5, .5), (0, 0, -1), (0, 1, 0)), ((1, -.5, -.5), (-2, 0, 0), (0, 1, 0)),
+            ((-1, -.5, -.5), (0, 0, 1), (0, 1, 0)), ((-1, .5, .5), (2, 0, 0), (0, 0, -1)), ((-1, -.5, -.5), (2, 0, 0), (0, 0, 1))]
+    for quad, (o, u, v) in zip(box.quads, want):
+        assert np.array_equal(list(quad.origin), o) and np.array_equal(list(quad.u), u) and np.array_equal(list(quad.v), v)
+    # translate / rotate accumulate in f32 like `+=` (instance.rs:234-243)
+    box.translate((0.1, 0.2, 0.3)); box.translate((0.1, 0.2, 0.3))
+    assert box.translation == [float(np.float32(0.1) + np.float32(0.1)), float(np.float32(0.2) + np.float32(0.2)), float(np.float32(0.3) + np.float32(0.3))]
+
+
+def test_scene_generate_geom_counts_capacity_and_pools():
+    L = R.lib()
+    counts = (C.c_uint32 * 5)()
+    bg = (C.c_float * 3)(9, 9, 9)
+    assert L.rtw_scene_generate_geom(R.SCENE_PRESENTATION, 42, None, None, None, None, None, None, counts, bg) == 0
+    assert list(counts) == [1, 6, 2, 0, 8] and list(bg) == [0, 0, 0]
+    quads = (R.RtwQuad * 6)()
+    small = (C.c_uint32 * 5)(1, 5, 2, 0, 8)                      # one quad short
+    assert L.rtw_scene_generate_geom(R.SCENE_PRESENTATION, 42, None, quads, None, None, None, small, counts, bg) == -1
+    assert L.rtw_scene_generate_geom(99, 42, None, None, None, None, None, None, counts, bg) == -1
+    sc = R.Scene.generate_geom(R.SCENE_PRESENTATION)
+    smoke, glass = sc._instances[0], sc._instances[1]
+    assert (smoke.first_quad, smoke.n_quads, smoke.medium, smoke.density) == (0, 6, R.MEDIUM_CONST_DENSITY, 2.0)
+    assert (glass.first_quad, glass.n_quads, glass.medium) == (6, 2, R.MEDIUM_SURFACE)
+    assert abs(smoke.rotation[1] - np.pi / 4) < 1e-7 and abs(glass.rotation[1] + np.pi / 6) < 1e-7
+    assert abs(glass.translation[0] - (2.0 - np.sqrt(np.float32(3.0)))) < 1e-7
+    assert [q.ir for q in list(sc._inst_quads)[6:8]] == [1.5, float(np.float32(2.0) / np.float32(3.0))]
+    light = sc._quads[1]
+    assert list(light.emitted) == [4, 4, 4] and (light.metallicness, light.opacity, light.ir) == (0.0, 0.0, 1.0)
+    # the sphere-only ids also work through the same entry point
+    assert L.rtw_scene_generate_geom(R.SCENE_C1, 42, None, None, None, None, None, None, counts, bg) == 0 and list(counts) == [3, 0, 0, 0, 0]
+    # the JSON wire format stays the reference's: spheres only (viewport.rs:174-180)
+    assert '"spheres"' in sc.to_json() and "quads" not in sc.to_json()
+
+
+def test_python_scene_flattens_instances_into_pools():
+    a = R.Instance.new([R.Sphere.new((0, 0, 0), 1.0)], [R.Quad.new((0, 0, 0), (1, 0, 0), (0, 1, 0))])
+    b = R.Instance.new_quads([R.Quad.new((0, 0, 1), (1, 0, 0), (0, 1, 0)), R.Quad.new((0, 0, 2), (1, 0, 0), (0, 1, 0))])
+    sc = R.Scene.new([], [R.Quad.new((0, 0, 3), (1, 0, 0), (0, 1, 0))], [a, b])
+    assert (sc.pod.n_spheres, sc.pod.n_quads, sc.pod.n_instances, sc.pod.n_inst_spheres, sc.pod.n_inst_quads) == (0, 1, 2, 1, 3)
+    i0, i1 = sc._instances[0], sc._instances[1]
+    assert (i0.first_sphere, i0.n_spheres, i0.first_quad, i0.n_quads) == (0, 1, 0, 1)
+    assert (i1.first_sphere, i1.n_spheres, i1.first_quad, i1.n_quads) == (1, 0, 1, 2)
+    assert [q.origin[2] for q in list(sc._inst_quads)[:3]] == [0.0, 1.0, 2.0]
