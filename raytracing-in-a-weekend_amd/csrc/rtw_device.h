@@ -73,20 +73,27 @@ __device__ __forceinline__ Rng rng_start(uint32_t base, uint32_t sample) {
     Rng r; r.state = mix32(base ^ sample); r.inc = mix32(r.state ^ 0x85EBCA6BU) | 1U;
     return r;
 }
-__device__ __forceinline__ float rng_f32(Rng &r) {
+// the top 24 bits of the next output, as a float: n in [0, 2^24), exact
+__device__ __forceinline__ float rng_n24(Rng &r) {
     uint32_t old = r.state;
     r.state = old * 747796405U + r.inc;
     uint32_t word = ((old >> ((old >> 28) + 4U)) ^ old) * 277803737U;
     word = (word >> 22) ^ word;
-    return (float)(word >> 8) * (1.0f / 16777216.0f);
+    return (float)(word >> 8);
 }
+__device__ __forceinline__ float rng_f32(Rng &r) { return rng_n24(r) * (1.0f / 16777216.0f); }
+// xi * 2 + (-1) and c + xi in ONE instruction each: n * 2^-k is exact (n < 2^24, power-of-two scale), so the fused
+// multiply-add rounds exactly once, at the same place as the reference's final addition -- bit-identical to
+// `random::<f32>() * (max - min) + min` (vec3.rs:221-227) and to `i as f32 + random::<f32>()` (viewport.rs:290).
+__device__ __forceinline__ float rng_sym(Rng &r) { return __builtin_fmaf(rng_n24(r), 1.0f / 8388608.0f, -1.0f); }
+__device__ __forceinline__ float rng_offset(Rng &r, float c) { return __builtin_fmaf(rng_n24(r), 1.0f / 16777216.0f, c); }
 // vec3.rs:228-239
 __device__ __forceinline__ v3 random_unit_vec(Rng &r) {
     v3 p;
     for (;;) {
-        p.x = rng_f32(r) * 2.0f + -1.0f;   // xi * (max - min) + min
-        p.y = rng_f32(r) * 2.0f + -1.0f;
-        p.z = rng_f32(r) * 2.0f + -1.0f;
+        p.x = rng_sym(r);                  // xi * (max - min) + min
+        p.y = rng_sym(r);
+        p.z = rng_sym(r);
         if (p.x * p.x + p.y * p.y + p.z * p.z <= 1.0f) break;
     }
     return unit(p);
@@ -94,8 +101,8 @@ __device__ __forceinline__ v3 random_unit_vec(Rng &r) {
 // vec3.rs:240-254
 __device__ __forceinline__ void random_in_unit_disk(Rng &r, float &px, float &py) {
     for (;;) {
-        px = rng_f32(r) * 2.0f - 1.0f;
-        py = rng_f32(r) * 2.0f - 1.0f;
+        px = rng_sym(r);                   // xi * 2.0 - 1.0
+        py = rng_sym(r);
         if (px * px + py * py <= 1.0f) break;
     }
 }

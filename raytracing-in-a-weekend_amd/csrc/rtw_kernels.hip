@@ -125,8 +125,8 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
             random_in_unit_disk(pt.rng, rx, ry);             // always drawn (viewport.rs:288)
             o = cam_o + (ld3(A.cam.u) * rx + ld3(A.cam.v) * ry) * A.cam.lens_radius;
             if (samp<SPEC>(A) == RTW_SAMPLER_ROW) {              // viewport.rs:290-297
-                jx = (float)px.i + rng_f32(pt.rng);
-                jy = (float)px.j + rng_f32(pt.rng);
+                jx = rng_offset(pt.rng, (float)px.i);
+                jy = rng_offset(pt.rng, (float)px.j);
                 tm = A.cam.time0 + A.cam.shutter * rng_f32(pt.rng);
             } else {                                         // viewport.rs:452-470 (x outer, y inner)
                 const uint32_t sx = px.s / A.s_root, sy = px.s % A.s_root;
@@ -640,6 +640,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
                     } else {
                         ph = trav_begin<MOVING>(A, pt, tr, n_tests);
                         inflight = true;
+
                     }
                 }
             }
@@ -658,7 +659,8 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
             c_steps[1]++; c_lanes[1] += nL;
             if (ph == PH_LEAF) {
                 const uint32_t s = (uint32_t)~tr.node;
-                exact_sphere<MOVING>(geom_in_lds ? lgeom[s] : sc.geom[s], MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
+                const f4 gs = geom_in_lds ? lgeom[s] : sc.geom[s];
+                exact_sphere<MOVING>(gs, MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
                 n_tests++;
                 tr.hi_lim = tr.best_t + tr.tau_t;
                 ph = trav_pop(tr, stack);
