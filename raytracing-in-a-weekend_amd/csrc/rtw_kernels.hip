@@ -276,6 +276,12 @@ __device__ __forceinline__ void flush_counters(const KArgs &A, uint32_t n_seg, u
     }
 }
 
+__device__ __forceinline__ void flush_tests(const KArgs &A, uint32_t n) {
+    unsigned long long q = n;
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&A.stats[2], q);
+}
+
 __device__ __forceinline__ void flush_quads(const KArgs &A, uint32_t n_quad) {
     unsigned long long q = n_quad;
     for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off);
@@ -413,7 +419,7 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 
 struct Trav {                // traversal state of one lane
     int node;                // >= 0 inner node to visit; < 0 leaf ~node to test
-    uint32_t sp;             // entries on this lane's LDS stack
+    uint32_t sp;             // BYTE offset of this lane's next free stack slot: (level * RTW_BLOCK + threadIdx.x) * sizeof(entry); level 0 == empty
     int best; float best_t;  // closest accepted hit so far (best_t starts at maxt)
     float a;                 // d.d
     float ix, iy, iz;        // 1/d
@@ -424,13 +430,21 @@ struct Trav {                // traversal state of one lane
 
 enum { PH_SHADE = 0, PH_TRAV = 1, PH_LEAF = 2, PH_DEAD = 3 };
 
+// Lanes of the wave for which `c` holds, as a 32-bit SGPR value.  The empty asm hides the popcount's origin from the
+// optimiser, which otherwise carries it as 64 bits and compares it with VALU v_cmp_*_u64 on scalar operands.
+__device__ __forceinline__ uint32_t lanes_in(bool c) {
+    uint32_t n = (uint32_t)__popcll(__ballot(c));
+    asm volatile("" : "+s"(n));
+    return n;
+}
+
 // Begin a closest-hit query: big spheres, per-ray constants, root.  Returns the phase to enter.
 template <bool MOVING>
-__device__ __forceinline__ int trav_begin(const KArgs &A, const Path &pt, Trav &tr, uint32_t &n_tests) {
+__device__ __forceinline__ int trav_begin(const KArgs &A, const Path &pt, Trav &tr) {
     const DevBvh &bv = A.bvh;
     const v3 o = pt.o, d = pt.d;
     tr.a = dot(d, d);
-    tr.best = -1; tr.best_t = A.maxt; tr.sp = 0;
+    tr.best = -1; tr.best_t = A.maxt; tr.sp = threadIdx.x * A.stack_entry;
     {   // big spheres: uniform loop, scalar loads
         cf4_ptr bg = (cf4_ptr)(uintptr_t)bv.big_geom;
         cf4_ptr bvel = (cf4_ptr)(uintptr_t)bv.big_vel;
@@ -438,7 +452,6 @@ __device__ __forceinline__ int trav_begin(const KArgs &A, const Path &pt, Trav &
             f4 vv = MOVING ? bvel[k] : f4{ 0, 0, 0, 0 };
             exact_sphere<MOVING>(bg[k], vv, bv.big_index[k], o, d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
         }
-        n_tests += bv.n_big;
     }
     tr.node = bv.root;
     if (tr.node == (int)0x80000000) return PH_SHADE;          // no tree: the query is complete
@@ -468,36 +481,41 @@ __device__ __forceinline__ int trav_begin(const KArgs &A, const Path &pt, Trav &
 // After a node/leaf step: take the next entry off the stack (or finish).
 template <class S>
 __device__ __forceinline__ int trav_pop(Trav &tr, const S *stack) {
-    if (tr.sp == 0) return PH_SHADE;
-    tr.sp--;
-    tr.node = (int)stack[tr.sp * RTW_BLOCK + threadIdx.x];
+    const uint32_t level = RTW_BLOCK * (uint32_t)sizeof(S);
+    if (tr.sp < level) return PH_SHADE;
+    tr.sp -= level;
+    tr.node = (int)*(const S *)((const unsigned char *)stack + tr.sp);
     return tr.node < 0 ? PH_LEAF : PH_TRAV;
 }
 
 // Both slab results are in: descend into the nearer child, push the farther (or pop).
 template <class S>
 __device__ __forceinline__ int trav_descend(Trav &tr, S *stack, float e0, float x0, float e1, float x1, int c0, int c1) {
-    const bool h0 = e0 <= x0 && x0 >= tr.lo_lim && e0 <= tr.hi_lim;
-    const bool h1 = e1 <= x1 && x1 >= tr.lo_lim && e1 <= tr.hi_lim;
+    // hit <=> [max(entry, lo_lim), min(exit, hi_lim)] is non-empty (lo_lim <= hi_lim always: best_t >= mint): two min/max and
+    // one compare per box instead of three compares and two mask ANDs
+    const float n0 = fmaxf(e0, tr.lo_lim), n1 = fmaxf(e1, tr.lo_lim);
+    const bool h0 = n0 <= fminf(x0, tr.hi_lim);
+    const bool h1 = n1 <= fminf(x1, tr.hi_lim);
 #if RTW_BRANCHLESS_DESCEND
     // select form: one predicated LDS write, one predicated LDS read, no nested exec-mask regions
     const bool both = h0 && h1, none = !h0 && !h1;
-    const bool near0 = h0 && (!h1 || e0 <= e1);
+    const bool near0 = h0 && (!h1 || n0 <= n1);
     const int nearc = near0 ? c0 : c1, farc = near0 ? c1 : c0;
-    if (both) stack[tr.sp * RTW_BLOCK + threadIdx.x] = (S)farc;
-    tr.sp += both ? 1u : 0u;
-    const bool pop = none && tr.sp != 0u;
+    const uint32_t level = RTW_BLOCK * (uint32_t)sizeof(S);
+    if (both) *(S *)((unsigned char *)stack + tr.sp) = (S)farc;
+    tr.sp += both ? level : 0u;
+    const bool pop = none && tr.sp >= level;
     int popped = 0;
-    if (pop) popped = (int)stack[(tr.sp - 1u) * RTW_BLOCK + threadIdx.x];
-    tr.sp -= pop ? 1u : 0u;
+    if (pop) popped = (int)*(const S *)((const unsigned char *)stack + (tr.sp - level));
+    tr.sp -= pop ? level : 0u;
     tr.node = none ? popped : nearc;
     if (none && !pop) return PH_SHADE;
     return tr.node < 0 ? PH_LEAF : PH_TRAV;
 #else
     if (h0 && h1) {
-        const bool near0 = e0 <= e1;
-        stack[tr.sp * RTW_BLOCK + threadIdx.x] = (S)(near0 ? c1 : c0);
-        tr.sp++;
+        const bool near0 = n0 <= n1;
+        *(S *)((unsigned char *)stack + tr.sp) = (S)(near0 ? c1 : c0);
+        tr.sp += RTW_BLOCK * (uint32_t)sizeof(S);
         tr.node = near0 ? c0 : c1;
         return tr.node < 0 ? PH_LEAF : PH_TRAV;
     }
@@ -581,16 +599,25 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     }
 
     int ph = PH_SHADE;
-    bool have = false, inflight = false, newpath = false;
+    // Lane flags live in ONE VGPR: as separate bools the compiler keeps them as lane masks in SGPR pairs and re-merges
+    // every one of them under exec on every trip of the loop (3 SALU each), although only SHADE steps change them.
+    enum : uint32_t { F_HAVE = 1u,       // owns a work unit
+                      F_INFLIGHT = 2u,   // a closest-hit query is in flight / complete and waiting to be shaded
+                      F_NEWPATH = 4u,    // the next SHADE step starts the next sample of the unit
+                      F_DONE = 8u };     // a finished path waits for the next SHADE step to bank it
+    uint32_t fl = 0u;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
     Reserve rs; rs.next = rs.end = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
-    Trav tr; tr.node = 0; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
+    Trav tr; tr.node = 0; tr.sp = threadIdx.x * (uint32_t)sizeof(stack_t); tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
-    uint32_t n_seg = 0, n_rays = 0, n_nodes = 0, n_tests = 0, n_quad = 0;
-    bool path_done = false;                         // a finished path waits for the next SHADE step to bank it
+    // Work counters live in SGPRs: they are sums of ballot popcounts the scheduler computes anyway (node visits ==
+    // lanes live in TRAVERSE steps, leaf tests == lanes live in LEAF steps), which keeps four VGPRs out of the loop.
+    // (32-bit: one wave's share of a launch -- at most 2^32 sample slots per launch, rtw_ctx_render -- stays far below 2^32)
+    uint32_t w_seg = 0, w_rays = 0;
+    uint32_t n_isph = 0, n_quad = 0;                // GEOM builds only: member-sphere and quad tests of the extra stage
     uint32_t c_steps[3] = { 0, 0, 0 };              // wave-uniform (SGPR) census of the scheduler
-    unsigned long long c_lanes[3] = { 0, 0, 0 };
+    uint32_t c_lanes[3] = { 0, 0, 0 };
 #ifdef RTW_STAMP
     unsigned long long c_time[3] = { 0, 0, 0 };
 #endif
@@ -600,9 +627,9 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         // SHADE is the expensive step (several hundred instructions): it runs when enough lanes have piled up
         // in it (RTW_S_HI) or when little traversal work is left to hide behind (RTW_T_LO); otherwise the
         // larger of the two traversal queues runs.
-        const uint32_t nT = (uint32_t)__popcll(__ballot(ph == PH_TRAV));
-        const uint32_t nL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
-        const uint32_t nS = (uint32_t)__popcll(__ballot(ph == PH_SHADE));
+        const uint32_t nT = lanes_in(ph == PH_TRAV);
+        const uint32_t nL = lanes_in(ph == PH_LEAF);
+        const uint32_t nS = lanes_in(ph == PH_SHADE);
         if ((nT | nL | nS) == 0u) break;                     // every lane is PH_DEAD
         const bool run_shade = nS >= RTW_S_HI || (nT < RTW_T_LO && nL < RTW_T_LO && nS > 0u);
         const bool run_leaf = nL > nT;
@@ -613,46 +640,47 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         if (run_shade) {
             c_steps[2]++; c_lanes[2] += nS;
             // a. the closest-hit query this lane was waiting on is complete: scatter, or end the path
-            bool need_unit = false;
+            bool need_unit = false, started = false;
+            w_seg += (uint32_t)__popcll(__ballot(ph == PH_SHADE && (fl & F_INFLIGHT) != 0u));
             if (ph == PH_SHADE) {
-                if (inflight) {
-                    inflight = false;
-                    n_seg++;
-                    path_done = GEOM ? shade_geom<MOVING>(A, pt, tr.best, tr.best_t, n_tests, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t);
+                if (fl & F_INFLIGHT) {
+                    fl &= ~F_INFLIGHT;
+                    const bool done = GEOM ? shade_geom<MOVING>(A, pt, tr.best, tr.best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t);
+                    if (done) fl |= F_DONE;
                 }
-                if (path_done) { path_done = false; if (finish_path(A, px, pt)) have = false; else newpath = true; }
-                need_unit = !have;
+                if (fl & F_DONE) { fl &= ~F_DONE; if (finish_path(A, px, pt)) fl &= ~F_HAVE; else fl |= F_NEWPATH; }
+                need_unit = (fl & F_HAVE) == 0u;
             }
             // b. next work unit.  Executed by EVERY lane of the wave (not only the ones in SHADE): the wave's
             //    reserve must stay wave-uniform, which it only does if all lanes run its bookkeeping.
             bool exhausted = false;
             const bool got = fetch_pixel(A, need_unit, px, exhausted, rs);
             if (ph == PH_SHADE) {
-                if (got) { have = true; newpath = true; }
+                if (got) fl |= F_HAVE | F_NEWPATH;
                 if (exhausted) ph = PH_DEAD;
-                if (have) {
+                if (fl & F_HAVE) {
                     // c. next camera ray (a lane whose path continues keeps its scattered ray)
-                    if (newpath) { newpath = false; start_path<SPEC>(A, px, pt); n_rays++; }
+                    if (fl & F_NEWPATH) { fl &= ~F_NEWPATH; start_path<SPEC>(A, px, pt); started = true; }
                     // d. start the next closest-hit query
                     if (!SPEC && A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
                         pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
-                        path_done = true;                                  // banked on the next SHADE trip
+                        fl |= F_DONE;                                      // banked on the next SHADE trip
                     } else {
-                        ph = trav_begin<MOVING>(A, pt, tr, n_tests);
-                        inflight = true;
-
+                        ph = trav_begin<MOVING>(A, pt, tr);
+                        fl |= F_INFLIGHT;
                     }
                 }
             }
+            w_rays += (uint32_t)__popcll(__ballot(started));
         } else if (!run_leaf) {
             // RTW_TRAV_UNROLL node visits per scheduling decision: the scheduler's ballots and branches are
             // paid once per burst; lanes that leave TRAVERSE (leaf reached / query done) sit out the rest of it.
             uint32_t live = nT;
             for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
                 c_steps[0]++; c_lanes[0] += live;
-                if (ph == PH_TRAV) { n_nodes++; ph = LDSN ? trav_node_lds((const u4 *)lnodes, tr, (short *)stack) : trav_node(A.bvh, tr, (int *)stack); }
+                if (ph == PH_TRAV) { ph = LDSN ? trav_node_lds((const u4 *)lnodes, tr, (short *)stack) : trav_node(A.bvh, tr, (int *)stack); }
                 if (u + 1 >= RTW_TRAV_UNROLL) break;
-                live = (uint32_t)__popcll(__ballot(ph == PH_TRAV));
+                live = lanes_in(ph == PH_TRAV);
                 if (live == 0u) break;
             }
         } else {
@@ -661,7 +689,6 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
                 const uint32_t s = (uint32_t)~tr.node;
                 const f4 gs = geom_in_lds ? lgeom[s] : sc.geom[s];
                 exact_sphere<MOVING>(gs, MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
-                n_tests++;
                 tr.hi_lim = tr.best_t + tr.tau_t;
                 ph = trav_pop(tr, stack);
             }
@@ -672,10 +699,13 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         c_time[which] += __builtin_amdgcn_s_memtime() - t_begin;
 #endif
     }
-    flush_counters(A, n_seg, n_rays, n_tests, n_nodes);
-    if (GEOM) flush_quads(A, n_quad);
+    if (GEOM) { flush_quads(A, n_quad); flush_tests(A, n_isph); }
     if ((threadIdx.x & 63u) == 0) {
-        for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[5 + k], (unsigned long long)c_steps[k]); atomicAdd(&A.stats[8 + k], c_lanes[k]); }
+        atomicAdd(&A.stats[0], (unsigned long long)w_rays);
+        atomicAdd(&A.stats[1], (unsigned long long)w_seg);
+        atomicAdd(&A.stats[2], (unsigned long long)c_lanes[1] + (unsigned long long)w_seg * A.bvh.n_big);   // leaf tests + the big-sphere pre-pass of every query
+        atomicAdd(&A.stats[3], (unsigned long long)c_lanes[0]);
+        for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[5 + k], (unsigned long long)c_steps[k]); atomicAdd(&A.stats[8 + k], (unsigned long long)c_lanes[k]); }
 #ifdef RTW_STAMP
         for (int k = 0; k < 3; k++) atomicAdd(&A.stats[11 + k], c_time[k]);
 #endif

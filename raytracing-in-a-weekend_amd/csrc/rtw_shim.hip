@@ -343,7 +343,8 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     if (p->accel == RTW_ACCEL_BVH) {
         const bool ldsn = a.bvh.nodes16 != nullptr;
         uint32_t levels = c->bvh.depth + 1; if (levels < 4) levels = 4; if (levels > RTW_BVH_STACK) levels = RTW_BVH_STACK;
-        uint32_t off = levels * RTW_BLOCK * (ldsn ? 2u : 4u);
+        a.stack_entry = ldsn ? 2u : 4u;
+        uint32_t off = levels * RTW_BLOCK * a.stack_entry;
         off = (off + 15u) & ~15u;
         if (ldsn) {
             a.lds_nodes_off = off; off += c->bvh.n_nodes * 32u; off = (off + 15u) & ~15u;
