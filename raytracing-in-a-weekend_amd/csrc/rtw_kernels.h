@@ -43,7 +43,6 @@ struct KArgs {
     uint32_t sampler, integrator, depth;
     uint32_t has_textures;        // any sphere with an image texture (selects the generic kernel)
     uint32_t lds_bytes;           // dynamic LDS of the BVH kernel: stack | f16 nodes | sphere geometry
-    uint32_t stack_entry;         // bytes per traversal-stack entry: 2 with LDS-resident nodes (16-bit ids), else 4
     uint32_t lds_nodes_off, lds_geom_off;   // byte offsets (16-aligned); geom_off == 0: geometry stays in global memory
     uint32_t seed_lo, seed_hi;
     float inv_gamma, mint, maxt;

@@ -407,9 +407,6 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 #ifndef RTW_S_HI
 #define RTW_S_HI 48u            /* lanes waiting in SHADE that trigger a SHADE step */
 #endif
-#ifndef RTW_BRANCHLESS_DESCEND
-#define RTW_BRANCHLESS_DESCEND 1   /* select form of the descend step: +2 % on the bench frame */
-#endif
 #ifndef RTW_TRAV_UNROLL
 #define RTW_TRAV_UNROLL 3       /* node visits per scheduling decision (1: 13.2, 2: 14.4, 3: 14.9, 4: 14.2 Gsegments/s) */
 #endif
@@ -418,8 +415,10 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 #endif
 
 struct Trav {                // traversal state of one lane
-    int node;                // >= 0 inner node to visit; < 0 leaf ~node to test
-    uint32_t sp;             // BYTE offset of this lane's next free stack slot: (level * RTW_BLOCK + threadIdx.x) * sizeof(entry); level 0 == empty
+    int node;                // the lane's PHASE is encoded here: 0 <= node < DEAD an inner node to visit (TRAVERSE); node < 0 the
+                             // leaf ~node to test (LEAF); END: no query pending, the lane waits for a SHADE step; DEAD: finished
+    uint32_t sp;             // BYTE offset of the TOP entry of this lane's stack, (level * RTW_BLOCK + threadIdx.x) * sizeof(entry);
+                             // level 0 holds the END sentinel, so a pop never has to ask whether the stack is empty
     int best; float best_t;  // closest accepted hit so far (best_t starts at maxt)
     float a;                 // d.d
     float ix, iy, iz;        // 1/d
@@ -428,7 +427,13 @@ struct Trav {                // traversal state of one lane
     float tau_t, lo_lim, hi_lim;
 };
 
-enum { PH_SHADE = 0, PH_TRAV = 1, PH_LEAF = 2, PH_DEAD = 3 };
+// Phase codes (stack entries are 16-bit when the nodes live in LDS, 32-bit otherwise).  Each phase test is ONE compare.
+template <class S> struct Code;
+template <> struct Code<short> { enum : int { END = 0x7FFF, DEAD = 0x7FFE }; };
+template <> struct Code<int> { enum : int { END = 0x7FFFFFFF, DEAD = 0x7FFFFFFE }; };
+template <class S> __device__ __forceinline__ bool in_trav(int node) { return (uint32_t)node < (uint32_t)Code<S>::DEAD; }
+__device__ __forceinline__ bool in_leaf(int node) { return node < 0; }
+template <class S> __device__ __forceinline__ bool in_shade(int node) { return node == (int)Code<S>::END; }
 
 // Lanes of the wave for which `c` holds, as a 32-bit SGPR value.  The empty asm hides the popcount's origin from the
 // optimiser, which otherwise carries it as 64 bits and compares it with VALU v_cmp_*_u64 on scalar operands.
@@ -438,13 +443,13 @@ __device__ __forceinline__ uint32_t lanes_in(bool c) {
     return n;
 }
 
-// Begin a closest-hit query: big spheres, per-ray constants, root.  Returns the phase to enter.
-template <bool MOVING>
-__device__ __forceinline__ int trav_begin(const KArgs &A, const Path &pt, Trav &tr) {
+// Begin a closest-hit query: big spheres, per-ray constants, root (which sets the phase).
+template <bool MOVING, class S>
+__device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav &tr) {
     const DevBvh &bv = A.bvh;
     const v3 o = pt.o, d = pt.d;
     tr.a = dot(d, d);
-    tr.best = -1; tr.best_t = A.maxt; tr.sp = threadIdx.x * A.stack_entry;
+    tr.best = -1; tr.best_t = A.maxt; tr.sp = threadIdx.x * (uint32_t)sizeof(S);
     {   // big spheres: uniform loop, scalar loads
         cf4_ptr bg = (cf4_ptr)(uintptr_t)bv.big_geom;
         cf4_ptr bvel = (cf4_ptr)(uintptr_t)bv.big_vel;
@@ -454,7 +459,7 @@ __device__ __forceinline__ int trav_begin(const KArgs &A, const Path &pt, Trav &
         }
     }
     tr.node = bv.root;
-    if (tr.node == (int)0x80000000) return PH_SHADE;          // no tree: the query is complete
+    if (tr.node == (int)0x80000000) { tr.node = (int)Code<S>::END; return; }   // no tree: the query is complete
     // per-ray constants of the thick-ray slab test.  Everything here only feeds CONSERVATIVE bounds, so
     // the hardware approximations (v_sqrt_f32 / v_rcp_f32 / v_rsq_f32, <= 1 ulp) are used with the
     // 1e-4 relative safety factors below instead of the correctly-rounded sequences.
@@ -475,57 +480,41 @@ __device__ __forceinline__ int trav_begin(const KArgs &A, const Path &pt, Trav &
     tr.kmx = -(o.x - rho) * ix; tr.kmy = -(o.y - rho) * iy; tr.kmz = -(o.z - rho) * iz;
     tr.lo_lim = A.mint - tr.tau_t;
     tr.hi_lim = tr.best_t + tr.tau_t;
-    return tr.node < 0 ? PH_LEAF : PH_TRAV;
 }
 
-// After a node/leaf step: take the next entry off the stack (or finish).
+// After a leaf test: take the next entry off the stack (the sentinel of level 0 ends the query).
 template <class S>
-__device__ __forceinline__ int trav_pop(Trav &tr, const S *stack) {
-    const uint32_t level = RTW_BLOCK * (uint32_t)sizeof(S);
-    if (tr.sp < level) return PH_SHADE;
-    tr.sp -= level;
-    tr.node = (int)*(const S *)((const unsigned char *)stack + tr.sp);
-    return tr.node < 0 ? PH_LEAF : PH_TRAV;
+__device__ __forceinline__ void trav_pop(Trav &tr, const unsigned char *stack) {
+    tr.node = (int)*(const S *)(stack + tr.sp);
+    tr.sp -= RTW_BLOCK * (uint32_t)sizeof(S);      // (may step below level 0 when the sentinel came off: sp is not used again before trav_begin)
 }
 
-// Both slab results are in: descend into the nearer child, push the farther (or pop).
+template <class S> __device__ __forceinline__ int entry_to_node(uint32_t raw);
+template <> __device__ __forceinline__ int entry_to_node<short>(uint32_t raw) { return (int)(short)raw; }
+template <> __device__ __forceinline__ int entry_to_node<int>(uint32_t raw) { return (int)raw; }
+
+// Both slab results are in: descend into the nearer child and push the farther, or pop.  Select form, no exec-mask regions:
+// the farther child is stored ABOVE the top unconditionally (it only counts when sp moves up), and the entry a pop would
+// return was read by the caller before the box tests (`popped`), so its LDS latency hides behind them.
+// c0 / c1 / popped are raw stack entries (for 16-bit entries: the id in the low half, upper bits ignored).
 template <class S>
-__device__ __forceinline__ int trav_descend(Trav &tr, S *stack, float e0, float x0, float e1, float x1, int c0, int c1) {
+__device__ __forceinline__ void trav_descend(Trav &tr, unsigned char *stack, float e0, float x0, float e1, float x1,
+                                             uint32_t c0, uint32_t c1, uint32_t popped) {
     // hit <=> [max(entry, lo_lim), min(exit, hi_lim)] is non-empty (lo_lim <= hi_lim always: best_t >= mint): two min/max and
     // one compare per box instead of three compares and two mask ANDs
     const float n0 = fmaxf(e0, tr.lo_lim), n1 = fmaxf(e1, tr.lo_lim);
     const bool h0 = n0 <= fminf(x0, tr.hi_lim);
     const bool h1 = n1 <= fminf(x1, tr.hi_lim);
-#if RTW_BRANCHLESS_DESCEND
-    // select form: one predicated LDS write, one predicated LDS read, no nested exec-mask regions
-    const bool both = h0 && h1, none = !h0 && !h1;
-    const bool near0 = h0 && (!h1 || n0 <= n1);
-    const int nearc = near0 ? c0 : c1, farc = near0 ? c1 : c0;
+    const bool both = h0 & h1, none = !(h0 | h1);
+    const bool near0 = h0 & (!h1 | (n0 <= n1));
     const uint32_t level = RTW_BLOCK * (uint32_t)sizeof(S);
-    if (both) *(S *)((unsigned char *)stack + tr.sp) = (S)farc;
-    tr.sp += both ? level : 0u;
-    const bool pop = none && tr.sp >= level;
-    int popped = 0;
-    if (pop) popped = (int)*(const S *)((const unsigned char *)stack + (tr.sp - level));
-    tr.sp -= pop ? level : 0u;
-    tr.node = none ? popped : nearc;
-    if (none && !pop) return PH_SHADE;
-    return tr.node < 0 ? PH_LEAF : PH_TRAV;
-#else
-    if (h0 && h1) {
-        const bool near0 = n0 <= n1;
-        *(S *)((unsigned char *)stack + tr.sp) = (S)(near0 ? c1 : c0);
-        tr.sp += RTW_BLOCK * (uint32_t)sizeof(S);
-        tr.node = near0 ? c0 : c1;
-        return tr.node < 0 ? PH_LEAF : PH_TRAV;
-    }
-    if (h0) { tr.node = c0; return c0 < 0 ? PH_LEAF : PH_TRAV; }
-    if (h1) { tr.node = c1; return c1 < 0 ? PH_LEAF : PH_TRAV; }
-    return trav_pop(tr, stack);
-#endif
+    *(S *)(stack + tr.sp + level) = (S)(near0 ? c1 : c0);
+    tr.node = entry_to_node<S>(none ? popped : (near0 ? c0 : c1));
+    tr.sp = (tr.sp + (both ? level : 0u)) - (none ? level : 0u);
 }
 
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u3 __attribute__((ext_vector_type(3)));
 // f16 halves of a dword as f32 (scalar casts only: element access through f16 ext-vectors is miscompiled
 // by this toolchain -- lanes came back undefined)
 __device__ __forceinline__ float h_lo(unsigned int w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)); }
@@ -533,10 +522,12 @@ __device__ __forceinline__ float h_hi(unsigned int w) { return (float)__builtin_
 
 // One inner-node visit, nodes resident in LDS as f16 (BvhNode16): two ds_read_b128 instead of four
 // global loads; the f16 planes feed v_fma_mix_f32 directly.
-__device__ __forceinline__ int trav_node_lds(const u4 *lnodes, Trav &tr, short *stack) {
-    const u4 r0 = lnodes[tr.node * 2], r1 = lnodes[tr.node * 2 + 1];
+__device__ __forceinline__ void trav_node_lds(const u4 *lnodes, Trav &tr, unsigned char *stack) {
+    const uint32_t popped = *(const unsigned short *)(stack + tr.sp);
+    const u4 r0 = lnodes[tr.node * 2];
+    const u3 r1 = *(const u3 *)(lnodes + tr.node * 2 + 1);     // 12 of the 16 bytes: no dead destination register for the allocator to recycle early
     // r0 = {lo0.x lo0.y} {lo0.z hi0.x} {hi0.y hi0.z} {lo1.x lo1.y}   r1 = {lo1.z hi1.x} {hi1.y hi1.z} {c0 c1} pad
-    const int c0 = (int)(short)(r1.z & 0xFFFFu), c1 = (int)(short)(r1.z >> 16);
+    const uint32_t c0 = r1.z, c1 = r1.z >> 16;
     float t1, t2;
     t1 = __builtin_fmaf(h_lo(r0.x), tr.ix, tr.kpx); t2 = __builtin_fmaf(h_hi(r0.y), tr.ix, tr.kmx);
     float e0 = fminf(t1, t2), x0 = fmaxf(t1, t2);
@@ -550,14 +541,15 @@ __device__ __forceinline__ int trav_node_lds(const u4 *lnodes, Trav &tr, short *
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
     t1 = __builtin_fmaf(h_lo(r1.x), tr.iz, tr.kpz); t2 = __builtin_fmaf(h_hi(r1.y), tr.iz, tr.kmz);
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
-    return trav_descend(tr, stack, e0, x0, e1, x1, c0, c1);
+    trav_descend<short>(tr, stack, e0, x0, e1, x1, c0, c1, popped);
 }
 
 // One inner-node visit: two slab tests, descend into the nearer child, push the farther.
-__device__ __forceinline__ int trav_node(const DevBvh &bv, Trav &tr, int *stack) {
+__device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr, unsigned char *stack) {
+    const uint32_t popped = *(const uint32_t *)(stack + tr.sp);
     const f4 *np = (const f4 *)(bv.nodes + tr.node);
     const f4 n0 = np[0], n1 = np[1], n2 = np[2];
-    const int c0 = bv.nodes[tr.node].c0, c1 = bv.nodes[tr.node].c1;
+    const uint32_t c0 = (uint32_t)bv.nodes[tr.node].c0, c1 = (uint32_t)bv.nodes[tr.node].c1;
     // child 0 box: lo0 = n0.xyz, hi0 = (n0.w, n1.x, n1.y); child 1: lo1 = (n1.z, n1.w, n2.x), hi1 = n2.yzw
     float t1, t2;
     t1 = __builtin_fmaf(n0.x, tr.ix, tr.kpx); t2 = __builtin_fmaf(n0.w, tr.ix, tr.kmx);
@@ -572,7 +564,7 @@ __device__ __forceinline__ int trav_node(const DevBvh &bv, Trav &tr, int *stack)
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
     t1 = __builtin_fmaf(n2.x, tr.iz, tr.kpz); t2 = __builtin_fmaf(n2.w, tr.iz, tr.kmz);
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
-    return trav_descend(tr, stack, e0, x0, e1, x1, c0, c1);
+    trav_descend<int>(tr, stack, e0, x0, e1, x1, c0, c1, popped);
 }
 
 #ifndef RTW_BVH_WAVES
@@ -581,12 +573,13 @@ __device__ __forceinline__ int trav_node(const DevBvh &bv, Trav &tr, int *stack)
 template <bool MOVING, bool LDSN, int SPEC, bool GEOM>
 __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bvh(const KArgs A) {
     // LDS is all dynamic, sized by the host for THIS tree (rtw_ctx_render): the per-lane traversal stack
-    // [level][thread] (a level is one conflict-free row; depth + 1 levels, 16-bit entries in the LDS-node
-    // variant), then -- LDS-node variant -- the f16 nodes and, when it does not cost a resident workgroup,
+    // [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel, one per tree level, and the slot
+    // above the top that the select-form descend always writes; 16-bit entries in the LDS-node variant), then -- LDS-node variant -- the f16 nodes and, when it does not cost a resident workgroup,
     // {centre, r^2} of every sphere for the leaf tests.  Book-1: 6 KB + 15.5 KB (+ 7.8 KB).
     typedef typename std::conditional<LDSN, short, int>::type stack_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    stack_t *stack = (stack_t *)lds_raw;
+    unsigned char *stack = lds_raw;
+    *(stack_t *)(stack + threadIdx.x * (uint32_t)sizeof(stack_t)) = (stack_t)Code<stack_t>::END;   // level 0: the sentinel (own slot, no sync needed)
     u4 *lnodes = (u4 *)(lds_raw + A.lds_nodes_off);
     f4 *lgeom = (f4 *)(lds_raw + A.lds_geom_off);
     const bool geom_in_lds = LDSN && A.lds_geom_off != 0u;
@@ -598,7 +591,6 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         __syncthreads();
     }
 
-    int ph = PH_SHADE;
     // Lane flags live in ONE VGPR: as separate bools the compiler keeps them as lane masks in SGPR pairs and re-merges
     // every one of them under exec on every trip of the loop (3 SALU each), although only SHADE steps change them.
     enum : uint32_t { F_HAVE = 1u,       // owns a work unit
@@ -609,7 +601,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
     Reserve rs; rs.next = rs.end = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
-    Trav tr; tr.node = 0; tr.sp = threadIdx.x * (uint32_t)sizeof(stack_t); tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
+    Trav tr; tr.node = (int)Code<stack_t>::END; tr.sp = threadIdx.x * (uint32_t)sizeof(stack_t); tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
     // Work counters live in SGPRs: they are sums of ballot popcounts the scheduler computes anyway (node visits ==
     // lanes live in TRAVERSE steps, leaf tests == lanes live in LEAF steps), which keeps four VGPRs out of the loop.
@@ -627,10 +619,10 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         // SHADE is the expensive step (several hundred instructions): it runs when enough lanes have piled up
         // in it (RTW_S_HI) or when little traversal work is left to hide behind (RTW_T_LO); otherwise the
         // larger of the two traversal queues runs.
-        const uint32_t nT = lanes_in(ph == PH_TRAV);
-        const uint32_t nL = lanes_in(ph == PH_LEAF);
-        const uint32_t nS = lanes_in(ph == PH_SHADE);
-        if ((nT | nL | nS) == 0u) break;                     // every lane is PH_DEAD
+        const uint32_t nT = lanes_in(in_trav<stack_t>(tr.node));
+        const uint32_t nL = lanes_in(in_leaf(tr.node));
+        const uint32_t nS = lanes_in(in_shade<stack_t>(tr.node));
+        if ((nT | nL | nS) == 0u) break;                     // every lane is DEAD
         const bool run_shade = nS >= RTW_S_HI || (nT < RTW_T_LO && nL < RTW_T_LO && nS > 0u);
         const bool run_leaf = nL > nT;
 #ifdef RTW_STAMP
@@ -641,8 +633,9 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
             c_steps[2]++; c_lanes[2] += nS;
             // a. the closest-hit query this lane was waiting on is complete: scatter, or end the path
             bool need_unit = false, started = false;
-            w_seg += (uint32_t)__popcll(__ballot(ph == PH_SHADE && (fl & F_INFLIGHT) != 0u));
-            if (ph == PH_SHADE) {
+            const bool shading = in_shade<stack_t>(tr.node);
+            w_seg += (uint32_t)__popcll(__ballot(shading && (fl & F_INFLIGHT) != 0u));
+            if (shading) {
                 if (fl & F_INFLIGHT) {
                     fl &= ~F_INFLIGHT;
                     const bool done = GEOM ? shade_geom<MOVING>(A, pt, tr.best, tr.best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t);
@@ -655,9 +648,9 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
             //    reserve must stay wave-uniform, which it only does if all lanes run its bookkeeping.
             bool exhausted = false;
             const bool got = fetch_pixel(A, need_unit, px, exhausted, rs);
-            if (ph == PH_SHADE) {
+            if (shading) {
                 if (got) fl |= F_HAVE | F_NEWPATH;
-                if (exhausted) ph = PH_DEAD;
+                if (exhausted) tr.node = (int)Code<stack_t>::DEAD;
                 if (fl & F_HAVE) {
                     // c. next camera ray (a lane whose path continues keeps its scattered ray)
                     if (fl & F_NEWPATH) { fl &= ~F_NEWPATH; start_path<SPEC>(A, px, pt); started = true; }
@@ -666,7 +659,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
                         pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
                         fl |= F_DONE;                                      // banked on the next SHADE trip
                     } else {
-                        ph = trav_begin<MOVING>(A, pt, tr);
+                        trav_begin<MOVING, stack_t>(A, pt, tr);
                         fl |= F_INFLIGHT;
                     }
                 }
@@ -678,19 +671,19 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
             uint32_t live = nT;
             for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
                 c_steps[0]++; c_lanes[0] += live;
-                if (ph == PH_TRAV) { ph = LDSN ? trav_node_lds((const u4 *)lnodes, tr, (short *)stack) : trav_node(A.bvh, tr, (int *)stack); }
+                if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr, stack); else trav_node(A.bvh, tr, stack); }
                 if (u + 1 >= RTW_TRAV_UNROLL) break;
-                live = lanes_in(ph == PH_TRAV);
+                live = lanes_in(in_trav<stack_t>(tr.node));
                 if (live == 0u) break;
             }
         } else {
             c_steps[1]++; c_lanes[1] += nL;
-            if (ph == PH_LEAF) {
+            if (in_leaf(tr.node)) {
                 const uint32_t s = (uint32_t)~tr.node;
                 const f4 gs = geom_in_lds ? lgeom[s] : sc.geom[s];
                 exact_sphere<MOVING>(gs, MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
                 tr.hi_lim = tr.best_t + tr.tau_t;
-                ph = trav_pop(tr, stack);
+                trav_pop<stack_t>(tr, stack);
             }
         }
 #ifdef RTW_STAMP

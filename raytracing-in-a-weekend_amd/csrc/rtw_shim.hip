@@ -342,9 +342,9 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     // dynamic LDS layout of the BVH kernel for this tree
     if (p->accel == RTW_ACCEL_BVH) {
         const bool ldsn = a.bvh.nodes16 != nullptr;
-        uint32_t levels = c->bvh.depth + 1; if (levels < 4) levels = 4; if (levels > RTW_BVH_STACK) levels = RTW_BVH_STACK;
-        a.stack_entry = ldsn ? 2u : 4u;
-        uint32_t off = levels * RTW_BLOCK * a.stack_entry;
+        // sentinel + one entry per tree level + the slot above the top the descend step always writes
+        uint32_t levels = c->bvh.depth + 3; if (levels < 4) levels = 4; if (levels > RTW_BVH_STACK + 3) levels = RTW_BVH_STACK + 3;
+        uint32_t off = levels * RTW_BLOCK * (ldsn ? 2u : 4u);
         off = (off + 15u) & ~15u;
         if (ldsn) {
             a.lds_nodes_off = off; off += c->bvh.n_nodes * 32u; off = (off + 15u) & ~15u;
