@@ -204,12 +204,12 @@ __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
 // Material::on_hit (materials.rs:105-154) followed by the degenerate-direction fix-up of
 // ray_color_* (ray_color.rs:31-33).  Returns the next direction; cos_theta for bg_color.
 struct MatP { float metallicness, opacity, ir; };   // the scalars of `Material` on_hit reads (materials.rs:15-20)
-__device__ __forceinline__ v3 on_hit(const MatP m, v3 normal, v3 dir, Rng &rng, float &cos_theta) {
+// `ud` is unit(dir), computed by the caller (the sky of a missing lane needs the same expression: one copy for the wave).
+__device__ __forceinline__ v3 on_hit(const MatP m, v3 normal, v3 dir, v3 ud, Rng &rng, float &cos_theta) {
     const bool front = !(dot(dir, normal) > 0.0f);
     // Shared by both branches: unit(dir), and its mirror direction.  reflect(ud, -n) == reflect(ud, n)
     // bit for bit ((-n*2) * dot(ud,-n) == (n*2) * dot(ud,n): negation is exact and commutes with the
     // rounded products and sums), so the dielectric's reflect about the ray-facing normal is this too.
-    const v3 ud = unit(dir);
     const v3 refl = reflect(ud, normal);
     v3 next;
     if (m.opacity > 0.0f) {
@@ -411,8 +411,7 @@ __device__ __forceinline__ bool geom_closest(const DevScene &sc, const DevGeom &
 }
 
 // ray_color.rs:38-40
-__device__ __forceinline__ v3 sky_gradient(v3 dir) {
-    v3 ud = unit(dir);
+__device__ __forceinline__ v3 sky_gradient(v3 ud) {      // ud = unit(direction)
     float t = 0.5f * (ud.y + 1.0f);
     return mk((1.0f - t) + t * 0.5f, (1.0f - t) + t * 0.7f, 1.0f);
 }

@@ -59,7 +59,11 @@ struct Path {             // the path a lane is tracing
 // Wave-local reserve of work items: the wave takes 64 consecutive items (one tile x chunk) from the global
 // queue with ONE atomic and hands them to its lanes as they run dry, so the queue word sees one atomic per
 // 64 units instead of one per refill (a single word saturates near 88 dequeues/us, MI355X_MICROARCH.md).
-struct Reserve { uint32_t next, end; };      // wave-uniform
+struct Reserve {                             // wave-uniform
+    uint32_t next, end;                      // items [next, end) of ONE 64-item block: the 64 pixels of one (tile, chunk) unit
+    uint32_t i0, k0;                         // the block's tile: first column, first compact row
+    uint32_t s0, s1;                         // the block's chunk: samples [s0, s1)
+};
 
 // Pull the next work item for the lanes with `need` set.  Must be called by all lanes of the wave
 // that are currently active; returns true for lanes that got a valid unit.  `exhausted` is set for
@@ -75,6 +79,15 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
         rs.next = base < A.total_work ? base : A.total_work;      // total_work is a multiple of 64
         rs.end = rs.next + (base < A.total_work ? 64u : 0u);
+        // Work unit = (8x8 tile, chunk of chunk_len samples, pixel of the tile); the units of one tile are consecutive.  The
+        // block's tile and chunk are the same for its 64 items: the three integer divisions run once per block, here.
+        const uint32_t u = rs.next >> 6;
+        const uint32_t tile = u / A.n_chunks, chunk = u - tile * A.n_chunks;
+        const uint32_t trow = tile / A.tiles_x, tcol = tile - trow * A.tiles_x;
+        rs.i0 = tcol * 8u;
+        rs.k0 = A.k_base + trow * 8u;
+        rs.s0 = chunk * A.chunk_len;
+        rs.s1 = rs.s0 + A.chunk_len < A.n_samples ? rs.s0 + A.chunk_len : A.n_samples;
     }
     const uint32_t avail = rs.end - rs.next;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -84,19 +97,19 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
     if (!need) return false;
     if (avail == 0u) { exhausted = true; return false; }          // the queue is empty
     if (rank >= avail) return false;                              // reserve ran out: next trip refills
-    // Work unit = (8x8 tile, chunk of RTW_CHUNK samples, pixel of the tile); units of one tile are consecutive,
-    // so the 64 lanes that pull together get the same chunk of the 64 pixels of one tile.
-    const uint32_t u = w >> 6, p = w & 63u;
-    const uint32_t tile = u / A.n_chunks, chunk = u - tile * A.n_chunks;
-    const uint32_t tcol = tile % A.tiles_x, trow = tile / A.tiles_x;
-    px.i = tcol * 8u + (p & 7u);
-    const uint32_t k = A.k_base + trow * 8u + (p >> 3);            // compact row of this partition
+    const uint32_t p = w & 63u;                                    // pixel of the tile
+    px.i = rs.i0 + (p & 7u);
+    const uint32_t k = rs.k0 + (p >> 3);                           // compact row of this partition
     if (!(px.i < A.width && k < A.k_end)) return false;            // padding item: ask again next trip
     px.j = k;   // compact row -> image row (RtwParams row partition)
-    if (A.part_count > 1) px.j = ((k / A.row_block) * A.part_count + A.part_index) * A.row_block + (k % A.row_block);
+    if (A.part_count > 1) {
+        // tiles are 8 rows tall and start on a multiple of 8, so with the usual 8-row blocks the block index is uniform too
+        if (A.row_block == 8u) px.j = ((rs.k0 >> 3) * A.part_count + A.part_index) * 8u + (p >> 3);
+        else px.j = ((k / A.row_block) * A.part_count + A.part_index) * A.row_block + (k % A.row_block);
+    }
     px.rng_base = rng_pixel_base(A.seed_lo, A.seed_hi, px.j * A.width + px.i);
-    px.s = chunk * A.chunk_len;
-    px.s_end = px.s + A.chunk_len < A.n_samples ? px.s + A.chunk_len : A.n_samples;
+    px.s = rs.s0;
+    px.s_end = rs.s1;
     px.slot = w * A.chunk_len;                                     // [unit][pixel of tile][sample of chunk]
     return px.s < px.s_end;
 }
@@ -141,18 +154,18 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
 
 // ray_color_* when the closest-hit query found nothing: sky / background ends the path.
 template <int SPEC>
-__device__ __forceinline__ void shade_miss(const KArgs &A, Path &pt) {
+__device__ __forceinline__ void shade_miss(const KArgs &A, Path &pt, v3 ud) {
     v3 miss;
     if (integ<SPEC>(A) == RTW_INTEGRATOR_BG_COLOR || integ<SPEC>(A) == RTW_INTEGRATOR_RUST2) miss = ld3(A.bg);
     else if (integ<SPEC>(A) == RTW_INTEGRATOR_FLAG) miss = mk(0.0f, 0.0f, 1.0f);
-    else miss = sky_gradient(pt.d);
+    else miss = sky_gradient(ud);
     pt.L = pt.L + miss * pt.thr;
 }
 
 // One step of ray_color_* at the closest hit, given as the reference's `Hit` (objects.rs:16-23): point, normal,
 // col_mod, material.  Returns true when the path is finished (pt.L is then its radiance).
 template <int SPEC>
-__device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 point, v3 normal, v3 cm, MatP mat, v3 emitted) {
+__device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 ud, v3 point, v3 normal, v3 cm, MatP mat, v3 emitted) {
     if (integ<SPEC>(A) == RTW_INTEGRATOR_NORMAL) {             // C++/src/tests.cpp:91
         pt.L = mk(normal.x + 1.0f, normal.y + 1.0f, normal.z + 1.0f) * 0.5f;
         return true;
@@ -171,7 +184,7 @@ __device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 point
         return false;
     }
     float cos_theta;
-    const v3 nd = on_hit(mat, normal, pt.d, pt.rng, cos_theta);
+    const v3 nd = on_hit(mat, normal, pt.d, ud, pt.rng, cos_theta);
     if (integ<SPEC>(A) == RTW_INTEGRATOR_BG_COLOR) {           // ray_color.rs:64-88, front-to-back
         // lambertian_scatter_pdf (materials.rs:5-13); pdf == 0 makes the reference's `color * pdf / pdf` a 0/0
         const float pdf = cos_theta > 0.0f ? cos_theta * 0.318309886183790671538f : 0.0f;
@@ -190,7 +203,7 @@ __device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 point
 
 // ... at top-level sphere `best` (Sphere::collision_normal's Hit, sphere.rs:124-146).
 template <bool MOVING, int SPEC>
-__device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, float best_t) {
+__device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, v3 ud, int best, float best_t) {
     const DevScene &sc = A.sc;
     f4 g = sc.geom[best];
     v3 c = mk(g.x, g.y, g.z);
@@ -200,13 +213,16 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, int best, fl
     const DevMat mat = sc.mat[best];
     const v3 cm = SPEC == 1 ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
     MatP m; m.metallicness = mat.metallicness; m.opacity = mat.opacity; m.ir = mat.ir;
-    return shade_surface<SPEC>(A, pt, point, normal, cm, m, ld3(mat.emitted));
+    return shade_surface<SPEC>(A, pt, ud, point, normal, cm, m, ld3(mat.emitted));
 }
 
 template <bool MOVING, int SPEC>
 __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float best_t) {
-    if (best < 0) { shade_miss<SPEC>(A, pt); return true; }
-    return shade_hit<MOVING, SPEC>(A, pt, best, best_t);
+    // unit(direction) feeds the scatter of the lanes that hit (materials.rs:111,143) and the sky of the lanes that missed
+    // (ray_color.rs:38): computed once, ahead of the divergent branches, instead of once in each
+    const v3 ud = unit(pt.d);
+    if (best < 0) { shade_miss<SPEC>(A, pt, ud); return true; }
+    return shade_hit<MOVING, SPEC>(A, pt, ud, best, best_t);
 }
 
 // Scenes with quads / instances (generic build only): finish Scene::collision_normal (viewport.rs:136-150) for
@@ -215,7 +231,7 @@ template <bool MOVING>
 __device__ __forceinline__ bool shade_geom(const KArgs &A, Path &pt, int best, float best_t, uint32_t &n_sph, uint32_t &n_quad) {
     GeomHit h;
     if (geom_closest(A.sc, A.geom, pt.o, pt.d, pt.tm, A.mint, A.maxt, best >= 0, best_t, pt.rng, h, n_sph, n_quad))
-        return shade_surface<0>(A, pt, h.point, h.normal, h.cm, h.m, h.emitted);
+        return shade_surface<0>(A, pt, unit(pt.d), h.point, h.normal, h.cm, h.m, h.emitted);
     return shade<MOVING, 0>(A, pt, best, best_t);
 }
 
@@ -339,7 +355,7 @@ template <bool MOVING, int SPEC, bool GEOM>
 __global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
-    Reserve rs; rs.next = rs.end = 0;
+    Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
     uint32_t n_seg = 0, n_rays = 0, n_isph = 0, n_quad = 0;
 
@@ -599,7 +615,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
                       F_DONE = 8u };     // a finished path waits for the next SHADE step to bank it
     uint32_t fl = 0u;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
-    Reserve rs; rs.next = rs.end = 0;
+    Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
     Trav tr; tr.node = (int)Code<stack_t>::END; tr.sp = threadIdx.x * (uint32_t)sizeof(stack_t); tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
