@@ -521,8 +521,10 @@ __device__ __forceinline__ void trav_descend(Trav &tr, unsigned char *stack, flo
     const float n0 = fmaxf(e0, tr.lo_lim), n1 = fmaxf(e1, tr.lo_lim);
     const bool h0 = n0 <= fminf(x0, tr.hi_lim);
     const bool h1 = n1 <= fminf(x1, tr.hi_lim);
-    const bool both = h0 & h1, none = !(h0 | h1);
-    const bool near0 = h0 & (!h1 | (n0 <= n1));
+    // (plain i1 logic on already-evaluated compares: lane-mask arithmetic on the scalar unit, no VALU and no branches)
+    const bool le = n0 <= n1;
+    const bool both = h0 && h1, none = !(h0 || h1);
+    const bool near0 = h0 && (!h1 || le);
     const uint32_t level = RTW_BLOCK * (uint32_t)sizeof(S);
     *(S *)(stack + tr.sp + level) = (S)(near0 ? c1 : c0);
     tr.node = entry_to_node<S>(none ? popped : (near0 ? c0 : c1));
