@@ -48,7 +48,34 @@ __device__ __forceinline__ v3 operator-(v3 a) { return mk(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float len2(v3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 __device__ __forceinline__ float len(v3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
-__device__ __forceinline__ v3 unit(v3 a) { return a / len(a); }
+// unit(a) = a / sqrt(a.a) (vec3.rs:213), correctly rounded sqrt and divisions.  hipcc expands every IEEE f32 sqrt to 17 and every
+// IEEE division to 12 instructions; most of those only serve operands near the ends of the exponent range (pre-scaling,
+// v_div_scale / v_div_fmas / v_div_fixup, the zero / inf / NaN classes).  When every lane of the wave has all three components
+// in [2^-40, 2^40] none of that can trigger: the sequence below is then the SAME arithmetic hipcc emits -- v_sqrt_f32 plus the
+// two one-ulp residual corrections; v_rcp_f32, its Newton step, and the three-fma quotient refinement -- with the scaling
+// steps (identities there) removed and the reciprocal shared by the three quotients: 36 instead of 58 VALU, same bits.
+// Any lane outside the range (a zero component, a denormal, an overflow) sends the whole wave down the generic expansion.
+__device__ __forceinline__ v3 unit(v3 a) {
+    const float lo = fminf(fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    const float hi = fmaxf(fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    const bool plain = lo >= 0x1p-40f && hi <= 0x1p40f;
+    if (__ballot(!plain) == 0ull) {
+        const float x = a.x * a.x + a.y * a.y + a.z * a.z;                     // in [2^-80, 2^82): no pre-scaling in sqrt
+        float s = __builtin_amdgcn_sqrtf(x);                                    // v_sqrt_f32, <= 1 ulp
+        const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+        const float e_dn = __builtin_fmaf(-s_dn, s, x), e_up = __builtin_fmaf(-s_up, s, x);
+        const float t = (0.0f >= e_dn) ? s_dn : s;
+        s = (0.0f < e_up) ? s_up : t;                                           // == the correctly rounded sqrt
+        float r = __builtin_amdgcn_rcpf(s);                                     // v_rcp_f32
+        r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);                  // one Newton step
+        v3 o;
+        { float q = a.x * r; q = __builtin_fmaf(__builtin_fmaf(-s, q, a.x), r, q); o.x = __builtin_fmaf(__builtin_fmaf(-s, q, a.x), r, q); }
+        { float q = a.y * r; q = __builtin_fmaf(__builtin_fmaf(-s, q, a.y), r, q); o.y = __builtin_fmaf(__builtin_fmaf(-s, q, a.y), r, q); }
+        { float q = a.z * r; q = __builtin_fmaf(__builtin_fmaf(-s, q, a.z), r, q); o.z = __builtin_fmaf(__builtin_fmaf(-s, q, a.z), r, q); }
+        return o;
+    }
+    return a / len(a);
+}
 // vec3.rs:256  self - (n * 2.0) * self.dot(n)
 __device__ __forceinline__ v3 reflect(v3 a, v3 n) { return a - (n * 2.0f) * dot(a, n); }
 __device__ __forceinline__ bool close_to_zero(v3 a) {
