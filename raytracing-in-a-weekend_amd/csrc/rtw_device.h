@@ -143,10 +143,20 @@ struct DevMat {
     float opacity;
     float ir;
     int32_t tex;
-    uint32_t pad0;
+    float inv_ir;         // 1.0 / ir                        } the material-only divisions of the dielectric branch
     float emitted[3];
-    uint32_t pad1;
+    float r0_front;       // ((1 - 1/ir) / (1 + 1/ir))^2     } (materials.rs:99-100,113), done once on the host: the same
+    float r0_back;        // ((1 - ir) / (1 + ir))^2         } single IEEE f32 operations, hoisted like radius * radius
+    uint32_t pad[3];
 };
+static_assert(sizeof(DevMat) == 64, "DevMat is four f4 rows");
+
+// The f32 operations of `reflectance` that depend on the material alone (materials.rs:99-100): r0 = ((1-x)/(1+x))^2.
+// __host__ __device__: the shim evaluates it once per sphere, the quad path per hit -- IEEE on both, same bits.
+__host__ __device__ __forceinline__ float schlick_r0(float ref_idx) {
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    return r0 * r0;
+}
 
 struct DevScene {
     const f4 *geom;
@@ -219,9 +229,7 @@ __device__ __forceinline__ v3 refract(v3 uv, v3 n, float etai_over_etat) {
     return r_out_perp + r_out_parallel;
 }
 // materials.rs:98-103, powi(5) = x * ((x*x)*(x*x))
-__device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
-    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
-    r0 = r0 * r0;
+__device__ __forceinline__ float reflectance(float cosine, float r0) {   // r0 = schlick_r0(ref_idx)
     float x = 1.0f - cosine;
     float x2 = x * x;
     float x5 = x * (x2 * x2);
@@ -230,7 +238,19 @@ __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
 
 // Material::on_hit (materials.rs:105-154) followed by the degenerate-direction fix-up of
 // ray_color_* (ray_color.rs:31-33).  Returns the next direction; cos_theta for bg_color.
-struct MatP { float metallicness, opacity, ir; };   // the scalars of `Material` on_hit reads (materials.rs:15-20)
+// The scalars of `Material` on_hit reads (materials.rs:15-20) plus the three values derived from `ir` alone.
+struct MatP { float metallicness, opacity, ir, inv_ir, r0_front, r0_back; };
+__device__ __forceinline__ MatP mat_params(float metallicness, float opacity, float ir) {   // derived values computed here (quads)
+    MatP m; m.metallicness = metallicness; m.opacity = opacity; m.ir = ir;
+    m.inv_ir = m.r0_front = m.r0_back = 0.0f;
+    if (opacity > 0.0f) { m.inv_ir = 1.0f / ir; m.r0_front = schlick_r0(m.inv_ir); m.r0_back = schlick_r0(ir); }   // read by the dielectric branch only
+    return m;
+}
+__device__ __forceinline__ MatP mat_params(const DevMat &d) {                                // ... or by the host (spheres)
+    MatP m; m.metallicness = d.metallicness; m.opacity = d.opacity; m.ir = d.ir;
+    m.inv_ir = d.inv_ir; m.r0_front = d.r0_front; m.r0_back = d.r0_back;
+    return m;
+}
 // `ud` is unit(dir), computed by the caller (the sky of a missing lane needs the same expression: one copy for the wave).
 __device__ __forceinline__ v3 on_hit(const MatP m, v3 normal, v3 dir, v3 ud, Rng &rng, float &cos_theta) {
     const bool front = !(dot(dir, normal) > 0.0f);
@@ -241,12 +261,12 @@ __device__ __forceinline__ v3 on_hit(const MatP m, v3 normal, v3 dir, v3 ud, Rng
     v3 next;
     if (m.opacity > 0.0f) {
         const v3 n = front ? normal : -normal;
-        const float ratio = front ? 1.0f / m.ir : m.ir;
+        const float ratio = front ? m.inv_ir : m.ir;
         float ct = dot(-ud, n);
         if (ct > 1.0f) ct = 1.0f;
         const float st = __builtin_sqrtf(1.0f - ct * ct);
         const bool cannot_refract = ratio * st > 1.0f;
-        const float rfl = reflectance(ct, ratio);
+        const float rfl = reflectance(ct, front ? m.r0_front : m.r0_back);
         bool do_reflect = cannot_refract;
         if (!do_reflect) do_reflect = rfl > rng_f32(rng);   // xi drawn only when refraction is possible
         next = do_reflect ? refl : refract(ud, n, ratio);
@@ -268,13 +288,13 @@ __device__ __forceinline__ v3 on_hit_rust2(const MatP m, v3 normal, v3 dir, Rng 
     if (m.opacity > 0.0f) {
         const bool front = !(dot(dir, normal) > 0.0f);
         const v3 n = front ? normal : -normal;
-        const float ratio = front ? 1.0f / m.ir : m.ir;
+        const float ratio = front ? m.inv_ir : m.ir;
         const v3 ud = unit(dir);
         float ct = dot(-ud, n);
         if (ct > 1.0f) ct = 1.0f;
         const float st = __builtin_sqrtf(1.0f - ct * ct);
         const bool cannot_refract = ratio * st > 1.0f;
-        const float rfl = reflectance(ct, ratio);
+        const float rfl = reflectance(ct, front ? m.r0_front : m.r0_back);
         bool do_reflect = cannot_refract;
         if (!do_reflect) do_reflect = rfl > rng_f32(rng);
         return do_reflect ? reflect(ud, n) : refract(ud, n, ratio);
@@ -356,7 +376,7 @@ __device__ __forceinline__ void quad_test(const DevScene &sc, const DevQuad *qua
     }
     found = true;
     h.t = t; h.point = point; h.normal = normal; h.cm = cm;
-    h.m.metallicness = r1.w; h.m.opacity = r2.w; h.m.ir = r3.w;
+    h.m = mat_params(r1.w, r2.w, r3.w);
     h.emitted = mk(r6.x, r6.y, r6.z);
 }
 
@@ -392,7 +412,7 @@ __device__ __forceinline__ bool instance_members(const DevScene &sc, const DevGe
         found = true;
         h.t = best_t; h.point = o + d * best_t; h.normal = unit(h.point - c);
         h.cm = sphere_albedo(sc, mat, h.normal);
-        h.m.metallicness = mat.metallicness; h.m.opacity = mat.opacity; h.m.ir = mat.ir;
+        h.m = mat_params(mat);
         h.emitted = ld3(mat.emitted);
     }
     for (uint32_t k = 0; k < in.n_quads; ++k) quad_test(sc, g.iquads, in.first_quad + k, o, d, mint, maxt, found, h);

@@ -212,8 +212,7 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, v3 ud, int b
     const v3 normal = unit(point - c);                       // sphere.rs:127
     const DevMat mat = sc.mat[best];
     const v3 cm = SPEC == 1 ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
-    MatP m; m.metallicness = mat.metallicness; m.opacity = mat.opacity; m.ir = mat.ir;
-    return shade_surface<SPEC>(A, pt, ud, point, normal, cm, m, ld3(mat.emitted));
+    return shade_surface<SPEC>(A, pt, ud, point, normal, cm, mat_params(mat), ld3(mat.emitted));
 }
 
 template <bool MOVING, int SPEC>

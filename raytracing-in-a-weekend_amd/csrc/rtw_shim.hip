@@ -62,6 +62,8 @@ static void prepare_spheres(const RtwSphere *sp, uint32_t n, std::vector<f4> &ge
             m.emitted[k] = s.emitted[k];
         }
         m.metallicness = s.metallicness; m.opacity = s.opacity; m.ir = s.ir; m.tex = s.tex;
+        m.inv_ir = host_div(1.0f, s.ir);                         // materials.rs:113  1.0 / self.ir
+        m.r0_front = schlick_r0(m.inv_ir); m.r0_back = schlick_r0(s.ir);   // materials.rs:99-100 for either ratio
     }
 }
 
