@@ -240,11 +240,14 @@ __device__ __forceinline__ float reflectance(float cosine, float r0) {   // r0 =
 // ray_color_* (ray_color.rs:31-33).  Returns the next direction; cos_theta for bg_color.
 // The scalars of `Material` on_hit reads (materials.rs:15-20) plus the three values derived from `ir` alone.
 struct MatP { float metallicness, opacity, ir, inv_ir, r0_front, r0_back; };
-__device__ __forceinline__ MatP mat_params(float metallicness, float opacity, float ir) {   // derived values computed here (quads)
+__device__ __forceinline__ MatP mat_params(float metallicness, float opacity, float ir) {   // quads: derived values follow in mat_derive()
     MatP m; m.metallicness = metallicness; m.opacity = opacity; m.ir = ir;
     m.inv_ir = m.r0_front = m.r0_back = 0.0f;
-    if (opacity > 0.0f) { m.inv_ir = 1.0f / ir; m.r0_front = schlick_r0(m.inv_ir); m.r0_back = schlick_r0(ir); }   // read by the dielectric branch only
     return m;
+}
+// ... once per query, for the quad that won (the values are read by the dielectric branch only)
+__device__ __forceinline__ void mat_derive(MatP &m) {
+    if (m.opacity > 0.0f) { m.inv_ir = 1.0f / m.ir; m.r0_front = schlick_r0(m.inv_ir); m.r0_back = schlick_r0(m.ir); }
 }
 __device__ __forceinline__ MatP mat_params(const DevMat &d) {                                // ... or by the host (spheres)
     MatP m; m.metallicness = d.metallicness; m.opacity = d.opacity; m.ir = d.ir;

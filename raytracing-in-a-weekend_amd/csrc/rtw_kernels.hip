@@ -229,8 +229,10 @@ __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float 
 template <bool MOVING>
 __device__ __forceinline__ bool shade_geom(const KArgs &A, Path &pt, int best, float best_t, uint32_t &n_sph, uint32_t &n_quad) {
     GeomHit h;
-    if (geom_closest(A.sc, A.geom, pt.o, pt.d, pt.tm, A.mint, A.maxt, best >= 0, best_t, pt.rng, h, n_sph, n_quad))
+    if (geom_closest(A.sc, A.geom, pt.o, pt.d, pt.tm, A.mint, A.maxt, best >= 0, best_t, pt.rng, h, n_sph, n_quad)) {
+        mat_derive(h.m);
         return shade_surface<0>(A, pt, unit(pt.d), h.point, h.normal, h.cm, h.m, h.emitted);
+    }
     return shade<MOVING, 0>(A, pt, best, best_t);
 }
 
@@ -351,7 +353,7 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
 }
 
 template <bool MOVING, int SPEC, bool GEOM>
-__global__ __launch_bounds__(RTW_BLOCK) void render_brute(const KArgs A) {
+__global__ __launch_bounds__(RTW_BLOCK, GEOM ? 4 : 1) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
     Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = 0;
