@@ -280,6 +280,25 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(c->device));
 
+    // The BVH's pruning is proven against the reference's ROUNDED quadratic (DESIGN.md "Conservative traversal"), which presumes
+    // that d.d is an ordinary f32.  Scattered directions are unit-scale by construction; camera directions are whatever the caller's
+    // camera says (the reference never normalises them), and when |d|^2 can overflow or underflow f32 the reference's quadratic
+    // degenerates -- NaN roots pass both range tests and are reported as hits (sphere.rs:118-121) -- which only the list walk
+    // reproduces.  Bound |d| over the image from the camera (d = pixel00 + x delta_u + y delta_v, x in [0,W], y in [0,H]):
+    // above by the triangle inequality, below by the distance of that plane from the origin; outside [1e-15, 1e15] walk the list.
+    uint32_t accel = p->accel;
+    if (accel == RTW_ACCEL_BVH) {
+        const double P[3] = { cam->pixel00[0], cam->pixel00[1], cam->pixel00[2] };
+        const double U[3] = { cam->delta_u[0], cam->delta_u[1], cam->delta_u[2] }, V[3] = { cam->delta_v[0], cam->delta_v[1], cam->delta_v[2] };
+        auto norm = [](const double *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+        const double W = (double)p->width + 1.0, H = (double)p->height + 1.0;
+        const double hi = norm(P) + W * norm(U) + H * norm(V);
+        const double N[3] = { U[1] * V[2] - U[2] * V[1], U[2] * V[0] - U[0] * V[2], U[0] * V[1] - U[1] * V[0] };
+        const double nn = norm(N);
+        const double lo = nn > 0.0 ? std::fabs(P[0] * N[0] + P[1] * N[1] + P[2] * N[2]) / nn : 0.0;
+        if (!(hi <= 1e15) || !(lo >= 1e-15)) accel = RTW_ACCEL_BRUTE;
+    }
+
     KArgs a;
     std::memset(&a, 0, sizeof a);
     a.cam = *cam; a.sc = c->sc; a.bvh = c->bvh; a.geom = c->geom;
@@ -342,7 +361,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     }
 
     // dynamic LDS layout of the BVH kernel for this tree
-    if (p->accel == RTW_ACCEL_BVH) {
+    if (accel == RTW_ACCEL_BVH) {
         const bool ldsn = a.bvh.nodes16 != nullptr;
         // sentinel + one entry per tree level + the slot above the top the descend step always writes
         uint32_t levels = c->bvh.depth + 3; if (levels < 4) levels = 4; if (levels > RTW_BVH_STACK + 3) levels = RTW_BVH_STACK + 3;
@@ -360,7 +379,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     }
 
     // persistent grid: as many workgroups as the kernel's registers let be resident, capped by the work
-    uint32_t per_cu = kernel_blocks_per_cu(a, c->sc.moving != 0, p->accel, c->bvh.nodes16 != nullptr && !(p->flags & RTW_FLAG_GLOBAL_NODES));
+    uint32_t per_cu = kernel_blocks_per_cu(a, c->sc.moving != 0, accel, c->bvh.nodes16 != nullptr && !(p->flags & RTW_FLAG_GLOBAL_NODES));
     if (const char *e = getenv("RTW_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = (uint32_t)v; }   // occupancy experiments
 
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream));
@@ -374,7 +393,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
         const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
         if (grid > need) grid = need ? need : 1;
         HIP_TRY(hipMemsetAsync(c->d_queue, 0, 64, c->stream));
-        if (a.n_tiles) launch_render(a, c->sc.moving != 0, p->accel, grid, c->stream);
+        if (a.n_tiles) launch_render(a, c->sc.moving != 0, accel, grid, c->stream);
         HIP_TRY(hipGetLastError());
         if (tile_rows == 0) break;
     }

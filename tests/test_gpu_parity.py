@@ -512,3 +512,31 @@ def test_mixed_scene_instances_with_spheres_textures_motion(gpu):
             # sphere / quad image textures go through atan2f / acosf / floorf of a product: a texel edge may fall differently
             assert same.mean() > 0.999, (integrator, accel, same.mean())
             assert np.nanmax(np.abs(np.where(np.isnan(ref), 0, img - ref))) < 1.0
+
+
+# ---- exponent-range edges: the guarded fast paths (unit(): shared reciprocal, unscaled sqrt) must agree with IEEE everywhere
+@pytest.mark.parametrize("log2_scale", [0, -70, 70, -126])
+def test_direction_scale_and_zero_components(gpu, log2_scale):
+    """Ray directions with exactly-zero components (the centre row / column of a power-of-two camera) and directions scaled by
+    2^-70 / 2^70 / 2^-126 (denormal components): every lane outside [2^-40, 2^40] sends its wave down the generic IEEE expansion,
+    and the image must stay bit-identical to the oracle either way.  At 2^70 |d|^2 overflows f32: the reference's quadratic then
+    reports NaN roots as hits, and the BVH kernel has to fall back to the list walk to reproduce that.  (The reference never normalises directions, so a scaled
+    camera is a legal input; scaling by a power of two scales every t exactly.)"""
+    scene = R.Scene.generate(R.SCENE_METAL_TEST)
+    sc = float(np.ldexp(1.0, log2_scale))
+    cam = R.RtwCamera()
+    for k, v in enumerate((-1.0 * sc, 0.5 * sc, -1.0 * sc)):
+        cam.pixel00[k] = v                               # pixel (8, 4) looks straight down -z: x == 0 and y == 0 exactly
+    cam.delta_u[0], cam.delta_v[1] = 0.125 * sc, -0.125 * sc
+    cam.u[0], cam.v[1] = 1.0, 1.0
+    vp = R.Viewport(cam, 16, 8, 32, 12, 1.0)
+    vp.mint, vp.maxt = 0.001 / sc if log2_scale > -100 else 0.001, min(1000.0 / sc, 3e38)
+    if log2_scale == -126:
+        vp.mint, vp.maxt = 1e30, 3e38                    # t = distance / |d| is ~1e38 here
+    for sampler in (R.SAMPLER_NO_RAND, R.SAMPLER_ROW):
+        p = vp.params(R.INTEGRATOR_GRADIENT, sampler)
+        ref, st_ref, out = render_both(gpu, scene, vp.camera(), p)
+        assert st_ref.segments > st_ref.camera_rays or log2_scale == -126      # something was hit and scattered
+        for accel, (img, st) in out.items():
+            assert st.segments == st_ref.segments, (log2_scale, sampler, accel)
+            assert np.array_equal(img, ref, equal_nan=True), (log2_scale, sampler, accel)
