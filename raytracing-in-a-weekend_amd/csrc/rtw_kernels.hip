@@ -434,7 +434,7 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 struct Trav {                // traversal state of one lane
     int node;                // the lane's PHASE is encoded here: 0 <= node < DEAD an inner node to visit (TRAVERSE); node < 0 the
                              // leaf ~node to test (LEAF); END: no query pending, the lane waits for a SHADE step; DEAD: finished
-    uint32_t sp;             // BYTE offset of the TOP entry of this lane's stack, (level * RTW_BLOCK + threadIdx.x) * sizeof(entry);
+    uint32_t sp;             // LDS byte ADDRESS of the TOP entry of this lane's stack, base + (level * RTW_BLOCK + threadIdx.x) * sizeof(entry);
                              // level 0 holds the END sentinel, so a pop never has to ask whether the stack is empty
     int best; float best_t;  // closest accepted hit so far (best_t starts at maxt)
     float a;                 // d.d
@@ -462,11 +462,11 @@ __device__ __forceinline__ uint32_t lanes_in(bool c) {
 
 // Begin a closest-hit query: big spheres, per-ray constants, root (which sets the phase).
 template <bool MOVING, class S>
-__device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav &tr) {
+__device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav &tr, uint32_t sp0) {
     const DevBvh &bv = A.bvh;
     const v3 o = pt.o, d = pt.d;
     tr.a = dot(d, d);
-    tr.best = -1; tr.best_t = A.maxt; tr.sp = threadIdx.x * (uint32_t)sizeof(S);
+    tr.best = -1; tr.best_t = A.maxt; tr.sp = sp0;           // the lane's level-0 slot (the sentinel)
     {   // big spheres: uniform loop, scalar loads
         cf4_ptr bg = (cf4_ptr)(uintptr_t)bv.big_geom;
         cf4_ptr bvel = (cf4_ptr)(uintptr_t)bv.big_vel;
@@ -499,10 +499,16 @@ __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav 
     tr.hi_lim = tr.best_t + tr.tau_t;
 }
 
+// The stack pointer is an ABSOLUTE LDS byte address (the dynamic-LDS base is already folded in when a query begins), so an
+// access is the ds instruction alone, no per-access address add.
+template <class T> __device__ __forceinline__ T lds_get(uint32_t addr) { return *(const __attribute__((address_space(3))) T *)(uintptr_t)addr; }
+template <class T> __device__ __forceinline__ void lds_put(uint32_t addr, T v) { *(__attribute__((address_space(3))) T *)(uintptr_t)addr = v; }
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
+
 // After a leaf test: take the next entry off the stack (the sentinel of level 0 ends the query).
 template <class S>
-__device__ __forceinline__ void trav_pop(Trav &tr, const unsigned char *stack) {
-    tr.node = (int)*(const S *)(stack + tr.sp);
+__device__ __forceinline__ void trav_pop(Trav &tr) {
+    tr.node = (int)lds_get<S>(tr.sp);
     tr.sp -= RTW_BLOCK * (uint32_t)sizeof(S);      // (may step below level 0 when the sentinel came off: sp is not used again before trav_begin)
 }
 
@@ -515,7 +521,7 @@ template <> __device__ __forceinline__ int entry_to_node<int>(uint32_t raw) { re
 // return was read by the caller before the box tests (`popped`), so its LDS latency hides behind them.
 // c0 / c1 / popped are raw stack entries (for 16-bit entries: the id in the low half, upper bits ignored).
 template <class S>
-__device__ __forceinline__ void trav_descend(Trav &tr, unsigned char *stack, float e0, float x0, float e1, float x1,
+__device__ __forceinline__ void trav_descend(Trav &tr, float e0, float x0, float e1, float x1,
                                              uint32_t c0, uint32_t c1, uint32_t popped) {
     // hit <=> [max(entry, lo_lim), min(exit, hi_lim)] is non-empty (lo_lim <= hi_lim always: best_t >= mint): two min/max and
     // one compare per box instead of three compares and two mask ANDs
@@ -527,7 +533,7 @@ __device__ __forceinline__ void trav_descend(Trav &tr, unsigned char *stack, flo
     const bool both = h0 && h1, none = !(h0 || h1);
     const bool near0 = h0 && (!h1 || le);
     const uint32_t level = RTW_BLOCK * (uint32_t)sizeof(S);
-    *(S *)(stack + tr.sp + level) = (S)(near0 ? c1 : c0);
+    lds_put<S>(tr.sp + level, (S)(near0 ? c1 : c0));
     tr.node = entry_to_node<S>(none ? popped : (near0 ? c0 : c1));
     tr.sp = (tr.sp + (both ? level : 0u)) - (none ? level : 0u);
 }
@@ -541,8 +547,8 @@ __device__ __forceinline__ float h_hi(unsigned int w) { return (float)__builtin_
 
 // One inner-node visit, nodes resident in LDS as f16 (BvhNode16): two ds_read_b128 instead of four
 // global loads; the f16 planes feed v_fma_mix_f32 directly.
-__device__ __forceinline__ void trav_node_lds(const u4 *lnodes, Trav &tr, unsigned char *stack) {
-    const uint32_t popped = *(const unsigned short *)(stack + tr.sp);
+__device__ __forceinline__ void trav_node_lds(const u4 *lnodes, Trav &tr) {
+    const uint32_t popped = lds_get<unsigned short>(tr.sp);
     const u4 r0 = lnodes[tr.node * 2];
     const u3 r1 = *(const u3 *)(lnodes + tr.node * 2 + 1);     // 12 of the 16 bytes: no dead destination register for the allocator to recycle early
     // r0 = {lo0.x lo0.y} {lo0.z hi0.x} {hi0.y hi0.z} {lo1.x lo1.y}   r1 = {lo1.z hi1.x} {hi1.y hi1.z} {c0 c1} pad
@@ -560,12 +566,12 @@ __device__ __forceinline__ void trav_node_lds(const u4 *lnodes, Trav &tr, unsign
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
     t1 = __builtin_fmaf(h_lo(r1.x), tr.iz, tr.kpz); t2 = __builtin_fmaf(h_hi(r1.y), tr.iz, tr.kmz);
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
-    trav_descend<short>(tr, stack, e0, x0, e1, x1, c0, c1, popped);
+    trav_descend<short>(tr, e0, x0, e1, x1, c0, c1, popped);
 }
 
 // One inner-node visit: two slab tests, descend into the nearer child, push the farther.
-__device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr, unsigned char *stack) {
-    const uint32_t popped = *(const uint32_t *)(stack + tr.sp);
+__device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr) {
+    const uint32_t popped = lds_get<uint32_t>(tr.sp);
     const f4 *np = (const f4 *)(bv.nodes + tr.node);
     const f4 n0 = np[0], n1 = np[1], n2 = np[2];
     const uint32_t c0 = (uint32_t)bv.nodes[tr.node].c0, c1 = (uint32_t)bv.nodes[tr.node].c1;
@@ -583,7 +589,7 @@ __device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr, unsigned c
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
     t1 = __builtin_fmaf(n2.x, tr.iz, tr.kpz); t2 = __builtin_fmaf(n2.w, tr.iz, tr.kmz);
     e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
-    trav_descend<int>(tr, stack, e0, x0, e1, x1, c0, c1, popped);
+    trav_descend<int>(tr, e0, x0, e1, x1, c0, c1, popped);
 }
 
 #ifndef RTW_BVH_WAVES
@@ -597,8 +603,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     // {centre, r^2} of every sphere for the leaf tests.  Book-1: 6 KB + 15.5 KB (+ 7.8 KB).
     typedef typename std::conditional<LDSN, short, int>::type stack_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned char *stack = lds_raw;
-    *(stack_t *)(stack + threadIdx.x * (uint32_t)sizeof(stack_t)) = (stack_t)Code<stack_t>::END;   // level 0: the sentinel (own slot, no sync needed)
+    *(stack_t *)(lds_raw + threadIdx.x * (uint32_t)sizeof(stack_t)) = (stack_t)Code<stack_t>::END;   // level 0: the sentinel (own slot, no sync needed)
     u4 *lnodes = (u4 *)(lds_raw + A.lds_nodes_off);
     f4 *lgeom = (f4 *)(lds_raw + A.lds_geom_off);
     const bool geom_in_lds = LDSN && A.lds_geom_off != 0u;
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
     Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
-    Trav tr; tr.node = (int)Code<stack_t>::END; tr.sp = threadIdx.x * (uint32_t)sizeof(stack_t); tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
+    Trav tr; tr.node = (int)Code<stack_t>::END; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
     // Work counters live in SGPRs: they are sums of ballot popcounts the scheduler computes anyway (node visits ==
     // lanes live in TRAVERSE steps, leaf tests == lanes live in LEAF steps), which keeps four VGPRs out of the loop.
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
                         pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
                         fl |= F_DONE;                                      // banked on the next SHADE trip
                     } else {
-                        trav_begin<MOVING, stack_t>(A, pt, tr);
+                        trav_begin<MOVING, stack_t>(A, pt, tr, lds_addr(lds_raw) + threadIdx.x * (uint32_t)sizeof(stack_t));
                         fl |= F_INFLIGHT;
                     }
                 }
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
             uint32_t live = nT;
             for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
                 c_steps[0]++; c_lanes[0] += live;
-                if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr, stack); else trav_node(A.bvh, tr, stack); }
+                if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr); else trav_node(A.bvh, tr); }
                 if (u + 1 >= RTW_TRAV_UNROLL) break;
                 live = lanes_in(in_trav<stack_t>(tr.node));
                 if (live == 0u) break;
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
                 const f4 gs = geom_in_lds ? lgeom[s] : sc.geom[s];
                 exact_sphere<MOVING>(gs, MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
                 tr.hi_lim = tr.best_t + tr.tau_t;
-                trav_pop<stack_t>(tr, stack);
+                trav_pop<stack_t>(tr);
             }
         }
 #ifdef RTW_STAMP
