@@ -48,6 +48,32 @@ __device__ __forceinline__ v3 operator-(v3 a) { return mk(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float len2(v3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 __device__ __forceinline__ float len(v3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+// ---- IEEE sqrt and division without the exponent-range machinery -----------------------------------------------------
+// hipcc expands a correctly rounded f32 sqrt to 17 and a division to 12 instructions; most of them (pre-scaling, v_div_scale /
+// v_div_fmas / v_div_fixup, the zero / inf / NaN classes) only serve operands near the ends of the exponent range.  The helpers
+// below are the SAME arithmetic with those steps -- identities for "plain" operands -- left out; callers check the operand
+// ranges for the whole wave (one ballot) and fall back to the generic expansion otherwise, so the bits never differ.
+//   sqrt_plain(x):  x in [2^-96, 2^127)        v_sqrt_f32 (<= 1 ulp) + the two one-ulp residual corrections
+//   rcp_refined(d), div_plain(n, d, r):  |d| in [2^-40, 2^40], |n| in [2^-60, 2^40]    v_rcp_f32 + one Newton step (shared by every
+//                   quotient over d), then the three-fma refinement of n * r
+__device__ __forceinline__ float sqrt_plain(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float e_dn = __builtin_fmaf(-s_dn, s, x), e_up = __builtin_fmaf(-s_up, s, x);
+    const float t = (0.0f >= e_dn) ? s_dn : s;
+    return (0.0f < e_up) ? s_up : t;
+}
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float div_plain(float n, float d, float r) {
+    float q = n * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+__device__ __forceinline__ bool in_range(float v, float lo, float hi) { const float a = __builtin_fabsf(v); return a >= lo && a <= hi; }
+
 // unit(a) = a / sqrt(a.a) (vec3.rs:213), correctly rounded sqrt and divisions.  hipcc expands every IEEE f32 sqrt to 17 and every
 // IEEE division to 12 instructions; most of those only serve operands near the ends of the exponent range (pre-scaling,
 // v_div_scale / v_div_fmas / v_div_fixup, the zero / inf / NaN classes).  When every lane of the wave has all three components
@@ -60,19 +86,9 @@ __device__ __forceinline__ v3 unit(v3 a) {
     const float hi = fmaxf(fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
     const bool plain = lo >= 0x1p-40f && hi <= 0x1p40f;
     if (__ballot(!plain) == 0ull) {
-        const float x = a.x * a.x + a.y * a.y + a.z * a.z;                     // in [2^-80, 2^82): no pre-scaling in sqrt
-        float s = __builtin_amdgcn_sqrtf(x);                                    // v_sqrt_f32, <= 1 ulp
-        const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
-        const float e_dn = __builtin_fmaf(-s_dn, s, x), e_up = __builtin_fmaf(-s_up, s, x);
-        const float t = (0.0f >= e_dn) ? s_dn : s;
-        s = (0.0f < e_up) ? s_up : t;                                           // == the correctly rounded sqrt
-        float r = __builtin_amdgcn_rcpf(s);                                     // v_rcp_f32
-        r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);                  // one Newton step
-        v3 o;
-        { float q = a.x * r; q = __builtin_fmaf(__builtin_fmaf(-s, q, a.x), r, q); o.x = __builtin_fmaf(__builtin_fmaf(-s, q, a.x), r, q); }
-        { float q = a.y * r; q = __builtin_fmaf(__builtin_fmaf(-s, q, a.y), r, q); o.y = __builtin_fmaf(__builtin_fmaf(-s, q, a.y), r, q); }
-        { float q = a.z * r; q = __builtin_fmaf(__builtin_fmaf(-s, q, a.z), r, q); o.z = __builtin_fmaf(__builtin_fmaf(-s, q, a.z), r, q); }
-        return o;
+        const float s = sqrt_plain(a.x * a.x + a.y * a.y + a.z * a.z);          // argument in [2^-80, 2^82)
+        const float r = rcp_refined(s);
+        return mk(div_plain(a.x, s, r), div_plain(a.y, s, r), div_plain(a.z, s, r));
     }
     return a / len(a);
 }
