@@ -16,7 +16,7 @@ struct DevBvh {
     const f4 *big_vel;
     const uint32_t *big_index;    // their indices in the scene list
     uint32_t n_big;
-    uint32_t depth;               // tree depth (the stack needs depth + 1 levels)
+    uint32_t depth;               // tree depth (the stack needs depth + 3 levels: sentinel, one per level, the slot above the top)
     int32_t root;                 // node index; ~sphere when the tree is a single leaf; INT32_MIN when empty
     float cx, cy, cz;             // centre C of the tree spheres' centres
     float centre_radius;          // R_c

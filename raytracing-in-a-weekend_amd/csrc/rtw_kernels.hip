@@ -22,7 +22,12 @@
 //   sphere test), SHADE (finish a segment: scatter / sky, next sample, next unit, set up the next
 //   traversal) -- and each loop trip executes ONE phase (ballot + popcount), the other lanes keep their
 //   state (traversal stack in LDS) and wait.  That turns three nested divergent loops into one loop whose
-//   body runs with most lanes live.
+//   body runs with most lanes live.  The phase is encoded in the lane's node register (Trav::node).
+// GEOM builds of both add the rest of Scene::collision_normal -- quads, instances, media -- to the SHADE step.
+//
+// What this code is tuned for: on MI355X the render time follows the number of VALU instructions issued
+//  -- so uniform work is kept on the scalar unit (lane-mask logic, counters as ballot popcounts,
+// the work-unit decode once per 64 items) and the divergent branches share what they can (one unit(direction)).
 #include "rtw_kernels.h"
 #include <type_traits>
 
