@@ -34,7 +34,7 @@ struct KArgs {
     uint32_t k_base, k_end;       // compact rows [k_base, k_end) of this partition rendered by this launch (a band)
     uint32_t n_tiles;             // tiles_x * ceil((k_end - k_base) / 8)
     uint32_t chunk_len, n_chunks; // samples per work unit, units per pixel
-    float *samples;               // per-sample radiance, [n_tiles * n_chunks][64][chunk_len][3]
+    float *samples;               // per-sample radiance, [n_tiles * n_chunks][chunk_len][64][3]
     uint32_t row_block, part_index, part_count;
     uint32_t tiles_x;             // ceil(width / 8)
     uint32_t total_work;          // 64 * n_tiles * n_chunks

@@ -115,7 +115,8 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
     px.rng_base = rng_pixel_base(A.seed_lo, A.seed_hi, px.j * A.width + px.i);
     px.s = rs.s0;
     px.s_end = rs.s1;
-    px.slot = w * A.chunk_len;                                     // [unit][pixel of tile][sample of chunk]
+    px.slot = (w >> 6) * 64u * A.chunk_len + (w & 63u);            // [unit][sample of chunk][pixel of tile]: lanes that finish the same
+                                                                   // sample of neighbouring pixels together fill whole sectors
     return px.s < px.s_end;
 }
 
@@ -246,13 +247,13 @@ __device__ __forceinline__ bool shade_geom(const KArgs &A, Path &pt, int best, f
 __device__ __forceinline__ bool finish_path(const KArgs &A, Pixel &px, Path &pt) {
     if (pt.poison) { const float qn = __builtin_nanf(""); pt.L = mk(qn, qn, qn); }
     *reinterpret_cast<float3 *>(A.samples + 3 * (size_t)px.slot) = make_float3(pt.L.x, pt.L.y, pt.L.z);   // one 12-byte store
-    px.slot++; px.s++;
+    px.slot += 64u; px.s++;
     return px.s >= px.s_end;
 }
 
 // The pixel stage of the driver (viewport.rs:299-301): color = sum of the samples IN ORDER, / samples,
 // powf(1/gamma), one coalesced-by-tile 12-byte store per pixel.  One lane per pixel; the per-sample radiances
-// were banked by the render kernel as [unit = tile*n_chunks + chunk][pixel of tile][sample of chunk].
+// were banked by the render kernel as [unit = tile*n_chunks + chunk][sample of chunk][pixel of tile].
 __global__ __launch_bounds__(RTW_BLOCK) void resolve_kernel(const KArgs A) {
     const uint32_t w = blockIdx.x * RTW_BLOCK + threadIdx.x;
     const uint32_t tile = w >> 6, p = w & 63u;
@@ -264,9 +265,9 @@ __global__ __launch_bounds__(RTW_BLOCK) void resolve_kernel(const KArgs A) {
             v3 acc = mk(0, 0, 0);
             uint32_t s = 0;
             for (uint32_t c = 0; c < A.n_chunks; c++) {
-                const float *src = A.samples + 3 * (size_t)(((tile * A.n_chunks + c) * 64u + p) * A.chunk_len);
+                const float *src = A.samples + 3 * ((size_t)(tile * A.n_chunks + c) * 64u * A.chunk_len + p);
                 const uint32_t cnt = s + A.chunk_len < A.n_samples ? A.chunk_len : A.n_samples - s;
-                for (uint32_t q = 0; q < cnt; q++) acc = acc + ld3(src + 3 * q);           // viewport.rs:299
+                for (uint32_t q = 0; q < cnt; q++) acc = acc + ld3(src + 3 * 64u * q);     // viewport.rs:299
                 s += cnt;
             }
             v3 col = acc / (float)A.n_samples;                   // viewport.rs:301
