@@ -540,3 +540,46 @@ def test_direction_scale_and_zero_components(gpu, log2_scale):
         for accel, (img, st) in out.items():
             assert st.segments == st_ref.segments, (log2_scale, sampler, accel)
             assert np.array_equal(img, ref, equal_nan=True), (log2_scale, sampler, accel)
+
+
+# ---- BVH stress: the conservative traversal must return the brute-force hit for adversarial geometry ------------------------
+@pytest.mark.parametrize("kind", ["dense_large", "radius_spread", "coincident_tangent", "moving_swarm"])
+def test_bvh_equals_brute_force_on_adversarial_scenes(gpu, kind):
+    """BVH vs the list walk (and vs the oracle), bit for bit, on scenes built to stress the pruning argument: thousands of
+    spheres (f32 nodes in global memory, deep tree), radii spread over 5 decades, exactly coincident / tangent / nested spheres
+    (ties in t must go to the lower index), and a swarm of fast movers whose bounds are time-expanded."""
+    rng = np.random.default_rng({"dense_large": 1, "radius_spread": 2, "coincident_tangent": 3, "moving_swarm": 4}[kind])
+    mats = [R.SCATTER_M, R.METALLIC_M, R.GLASS_M, R.FUZZY3_M, R.GLASSR_M]
+    spheres = []
+    shutter = 0.0
+    if kind == "dense_large":
+        for i in range(3000):
+            spheres.append(R.Sphere.with_albedo(rng.uniform(-12, 12, 3) + [0, 0, -14], float(rng.uniform(0.05, 0.5)), rng.uniform(0.2, 0.95, 3), mats[i % 5]))
+    elif kind == "radius_spread":
+        for i in range(700):
+            r = float(10.0 ** rng.uniform(-3.5, 1.2))
+            spheres.append(R.Sphere.with_albedo(rng.uniform(-6, 6, 3) * (1 + r) + [0, 0, -10 - 2 * r], r, rng.uniform(0.2, 0.95, 3), mats[i % 5]))
+    elif kind == "coincident_tangent":
+        for i in range(40):
+            c = np.round(rng.uniform(-3, 3, 3) * 4) / 4 + [0, 0, -6]
+            r = float(rng.choice([0.25, 0.5]))
+            spheres.append(R.Sphere.with_albedo(c, r, rng.uniform(0.2, 0.95, 3), mats[i % 5]))
+            spheres.append(R.Sphere.with_albedo(c, r, rng.uniform(0.2, 0.95, 3), mats[(i + 1) % 5]))                  # exactly coincident
+            spheres.append(R.Sphere.with_albedo(c + [2 * r, 0, 0], r, rng.uniform(0.2, 0.95, 3), mats[(i + 2) % 5]))   # tangent
+            spheres.append(R.Sphere.with_albedo(c, r / 2, rng.uniform(0.2, 0.95, 3), mats[(i + 3) % 5]))              # nested, concentric
+    else:
+        shutter = 1.0 / 30.0
+        for i in range(600):
+            s = R.Sphere.with_albedo(rng.uniform(-5, 5, 3) + [0, 0, -8], float(rng.uniform(0.05, 0.3)), rng.uniform(0.2, 0.95, 3), mats[i % 5],
+                                     velocity=tuple(rng.uniform(-60, 60, 3)))                               # up to 2 units per shutter
+            spheres.append(s)
+    scene = R.Scene(spheres)
+    vp = R.Viewport.new_from_res(128, 72, 8, 10, 1.0, vfov=70.0, lens_radius=0.01)
+    vp.shutter_speed, vp.fps = shutter, 30.0
+    cam = vp.camera()
+    p = vp.params(R.INTEGRATOR_GRADIENT, R.SAMPLER_ROW)
+    ref, st_ref, out = render_both(gpu, scene, cam, p)
+    for accel, (img, st) in out.items():
+        assert st.segments == st_ref.segments, (kind, accel)
+        assert np.array_equal(img, ref), (kind, accel, int((img != ref).any(axis=2).sum()))
+    assert out[R.ACCEL_BVH][1].node_tests > 0
