@@ -641,8 +641,8 @@ void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end,
         for (size_t i = 0; i < out.nodes.size(); i++) {
             const BvhNode &a = out.nodes[i]; BvhNode16 &b = out.nodes16[i];
             for (int k = 0; k < 3; k++) {
-                b.lo0[k] = half_bits(a.lo0[k], false); b.hi0[k] = half_bits(a.hi0[k], true);
-                b.lo1[k] = half_bits(a.lo1[k], false); b.hi1[k] = half_bits(a.hi1[k], true);
+                b.plane[0][k][0] = half_bits(a.lo0[k], false); b.plane[0][k][1] = half_bits(a.hi0[k], true);
+                b.plane[1][k][0] = half_bits(a.lo1[k], false); b.plane[1][k][1] = half_bits(a.hi1[k], true);
             }
             b.c0 = (int16_t)a.c0; b.c1 = (int16_t)a.c1; b.pad = 0;
         }
@@ -696,7 +696,7 @@ extern "C" int rtw_bvh_validate(const RtwScene *sc, float t_begin, float t_end, 
                 if (!(ch.lo[k] >= it.lo[k] && ch.hi[k] <= it.hi[k] && ch.lo[k] <= ch.hi[k])) return RTW_E_INVALID;
                 if (!b.nodes16.empty()) {
                     const BvhNode16 &h = b.nodes16[it.ref];
-                    const float l16 = half(c ? h.lo1[k] : h.lo0[k]), h16 = half(c ? h.hi1[k] : h.hi0[k]);
+                    const float l16 = half(h.plane[c][k][0]), h16 = half(h.plane[c][k][1]);
                     if (!(l16 <= ch.lo[k] && h16 >= ch.hi[k])) return RTW_E_INVALID;
                     if ((int32_t)(c ? h.c1 : h.c0) != ch.ref) return RTW_E_INVALID;
                 }

@@ -27,9 +27,10 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
 // Compact node for the LDS-resident variant: the same two child boxes as f16, rounded OUTWARD (lo down,
 // hi up: the tree only prunes, so larger boxes stay conservative), 16-bit child ids.  32 bytes.
+// One dword per (box, axis) holding {lo, hi}: the kernel swaps the halves with ONE v_perm_b32 when the ray
+// runs against the axis and has its {near plane, far plane} without a min / max pair.
 struct BvhNode16 {
-    uint16_t lo0[3], hi0[3];
-    uint16_t lo1[3], hi1[3];
+    uint16_t plane[2][3][2];   // [child box][axis]{lo, hi}
     int16_t c0, c1;
     uint32_t pad;
 };

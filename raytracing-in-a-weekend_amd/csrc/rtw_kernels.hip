@@ -445,8 +445,9 @@ struct Trav {                // traversal state of one lane
     int best; float best_t;  // closest accepted hit so far (best_t starts at maxt)
     float a;                 // d.d
     float ix, iy, iz;        // 1/d
-    float kpx, kpy, kpz;     // -(o + rho) / d
-    float kmx, kmy, kmz;     // -(o - rho) / d
+    float kpx, kpy, kpz;     // global-node variant: -(o + rho) / d (goes with a box's lo planes); LDS variant: the NEAR planes' constant
+    float kmx, kmy, kmz;     // global-node variant: -(o - rho) / d (hi planes);                    LDS variant: the FAR planes' constant
+    uint32_t selx, sely, selz;   // LDS variant: v_perm_b32 selector per axis, identity when the ray runs along +axis, half-swap otherwise
     float tau_t, lo_lim, hi_lim;
 };
 
@@ -499,8 +500,19 @@ __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav 
     if (!(fabsf(d.z) >= 1e-20f)) iz = copysignf(1e20f, d.z);
     tr.ix = ix; tr.iy = iy; tr.iz = iz;
     // t(lo) = (lo - rho - o) * inv = fma(lo, inv, -(o + rho) * inv);  t(hi) = fma(hi, inv, -(o - rho) * inv)
-    tr.kpx = -(o.x + rho) * ix; tr.kpy = -(o.y + rho) * iy; tr.kpz = -(o.z + rho) * iz;
-    tr.kmx = -(o.x - rho) * ix; tr.kmy = -(o.y - rho) * iy; tr.kmz = -(o.z - rho) * iz;
+    const float kpx = -(o.x + rho) * ix, kpy = -(o.y + rho) * iy, kpz = -(o.z + rho) * iz;
+    const float kmx = -(o.x - rho) * ix, kmy = -(o.y - rho) * iy, kmz = -(o.z - rho) * iz;
+    if (sizeof(S) == 2) {
+        // LDS nodes: a ray along +axis enters through lo (t(lo) <= t(hi): km - kp = 2 rho inv >= 0) and one along -axis through
+        // hi (then km <= kp), so {near, far} = {lo, hi} or {hi, lo} by the sign of 1/d alone -- the same two numbers min / max
+        // would pick, chosen by one byte permute of the {lo, hi} dword instead of a v_min / v_max pair per plane pair.
+        const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
+        tr.kpx = nx ? kmx : kpx; tr.kmx = nx ? kpx : kmx; tr.selx = nx ? 0x01000302u : 0x03020100u;
+        tr.kpy = ny ? kmy : kpy; tr.kmy = ny ? kpy : kmy; tr.sely = ny ? 0x01000302u : 0x03020100u;
+        tr.kpz = nz ? kmz : kpz; tr.kmz = nz ? kpz : kmz; tr.selz = nz ? 0x01000302u : 0x03020100u;
+    } else {
+        tr.kpx = kpx; tr.kpy = kpy; tr.kpz = kpz; tr.kmx = kmx; tr.kmy = kmy; tr.kmz = kmz;
+    }
     tr.lo_lim = A.mint - tr.tau_t;
     tr.hi_lim = tr.best_t + tr.tau_t;
 }
@@ -557,21 +569,15 @@ __device__ __forceinline__ void trav_node_lds(const u4 *lnodes, Trav &tr) {
     const uint32_t popped = lds_get<unsigned short>(tr.sp);
     const u4 r0 = lnodes[tr.node * 2];
     const u3 r1 = *(const u3 *)(lnodes + tr.node * 2 + 1);     // 12 of the 16 bytes: no dead destination register for the allocator to recycle early
-    // r0 = {lo0.x lo0.y} {lo0.z hi0.x} {hi0.y hi0.z} {lo1.x lo1.y}   r1 = {lo1.z hi1.x} {hi1.y hi1.z} {c0 c1} pad
+    // r0 = box0 {lo hi}.x  box0 {lo hi}.y  box0 {lo hi}.z  box1 {lo hi}.x      r1 = box1 {lo hi}.y  box1 {lo hi}.z  {c0 c1}
     const uint32_t c0 = r1.z, c1 = r1.z >> 16;
-    float t1, t2;
-    t1 = __builtin_fmaf(h_lo(r0.x), tr.ix, tr.kpx); t2 = __builtin_fmaf(h_hi(r0.y), tr.ix, tr.kmx);
-    float e0 = fminf(t1, t2), x0 = fmaxf(t1, t2);
-    t1 = __builtin_fmaf(h_hi(r0.x), tr.iy, tr.kpy); t2 = __builtin_fmaf(h_lo(r0.z), tr.iy, tr.kmy);
-    e0 = fmaxf(e0, fminf(t1, t2)); x0 = fminf(x0, fmaxf(t1, t2));
-    t1 = __builtin_fmaf(h_lo(r0.y), tr.iz, tr.kpz); t2 = __builtin_fmaf(h_hi(r0.z), tr.iz, tr.kmz);
-    e0 = fmaxf(e0, fminf(t1, t2)); x0 = fminf(x0, fmaxf(t1, t2));
-    t1 = __builtin_fmaf(h_lo(r0.w), tr.ix, tr.kpx); t2 = __builtin_fmaf(h_hi(r1.x), tr.ix, tr.kmx);
-    float e1 = fminf(t1, t2), x1 = fmaxf(t1, t2);
-    t1 = __builtin_fmaf(h_hi(r0.w), tr.iy, tr.kpy); t2 = __builtin_fmaf(h_lo(r1.y), tr.iy, tr.kmy);
-    e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
-    t1 = __builtin_fmaf(h_lo(r1.x), tr.iz, tr.kpz); t2 = __builtin_fmaf(h_hi(r1.y), tr.iz, tr.kmz);
-    e1 = fmaxf(e1, fminf(t1, t2)); x1 = fminf(x1, fmaxf(t1, t2));
+    // {near plane, far plane} of each (box, axis): the halves as stored or swapped, by the ray's direction along the axis
+    const uint32_t ax = __builtin_amdgcn_perm(r0.x, r0.x, tr.selx), ay = __builtin_amdgcn_perm(r0.y, r0.y, tr.sely), az = __builtin_amdgcn_perm(r0.z, r0.z, tr.selz);
+    const uint32_t bx = __builtin_amdgcn_perm(r0.w, r0.w, tr.selx), by = __builtin_amdgcn_perm(r1.x, r1.x, tr.sely), bz = __builtin_amdgcn_perm(r1.y, r1.y, tr.selz);
+    const float e0 = fmaxf(fmaxf(__builtin_fmaf(h_lo(ax), tr.ix, tr.kpx), __builtin_fmaf(h_lo(ay), tr.iy, tr.kpy)), __builtin_fmaf(h_lo(az), tr.iz, tr.kpz));
+    const float x0 = fminf(fminf(__builtin_fmaf(h_hi(ax), tr.ix, tr.kmx), __builtin_fmaf(h_hi(ay), tr.iy, tr.kmy)), __builtin_fmaf(h_hi(az), tr.iz, tr.kmz));
+    const float e1 = fmaxf(fmaxf(__builtin_fmaf(h_lo(bx), tr.ix, tr.kpx), __builtin_fmaf(h_lo(by), tr.iy, tr.kpy)), __builtin_fmaf(h_lo(bz), tr.iz, tr.kpz));
+    const float x1 = fminf(fminf(__builtin_fmaf(h_hi(bx), tr.ix, tr.kmx), __builtin_fmaf(h_hi(by), tr.iy, tr.kmy)), __builtin_fmaf(h_hi(bz), tr.iz, tr.kmz));
     trav_descend<short>(tr, e0, x0, e1, x1, c0, c1, popped);
 }
 
@@ -632,7 +638,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
     Trav tr; tr.node = (int)Code<stack_t>::END; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
-    tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
+    tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.selx = tr.sely = tr.selz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
     // Work counters live in SGPRs: they are sums of ballot popcounts the scheduler computes anyway (node visits ==
     // lanes live in TRAVERSE steps, leaf tests == lanes live in LEAF steps), which keeps four VGPRs out of the loop.
     // (32-bit: one wave's share of a launch -- at most 2^32 sample slots per launch, rtw_ctx_render -- stays far below 2^32)
