@@ -499,19 +499,23 @@ __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav 
     if (!(fabsf(d.y) >= 1e-20f)) iy = copysignf(1e20f, d.y);
     if (!(fabsf(d.z) >= 1e-20f)) iz = copysignf(1e20f, d.z);
     tr.ix = ix; tr.iy = iy; tr.iz = iz;
-    // t(lo) = (lo - rho - o) * inv = fma(lo, inv, -(o + rho) * inv);  t(hi) = fma(hi, inv, -(o - rho) * inv)
-    const float kpx = -(o.x + rho) * ix, kpy = -(o.y + rho) * iy, kpz = -(o.z + rho) * iz;
-    const float kmx = -(o.x - rho) * ix, kmy = -(o.y - rho) * iy, kmz = -(o.z - rho) * iz;
     if (sizeof(S) == 2) {
-        // LDS nodes: a ray along +axis enters through lo (t(lo) <= t(hi): km - kp = 2 rho inv >= 0) and one along -axis through
-        // hi (then km <= kp), so {near, far} = {lo, hi} or {hi, lo} by the sign of 1/d alone -- the same two numbers min / max
-        // would pick, chosen by one byte permute of the {lo, hi} dword instead of a v_min / v_max pair per plane pair.
-        const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
-        tr.kpx = nx ? kmx : kpx; tr.kmx = nx ? kpx : kmx; tr.selx = nx ? 0x01000302u : 0x03020100u;
-        tr.kpy = ny ? kmy : kpy; tr.kmy = ny ? kpy : kmy; tr.sely = ny ? 0x01000302u : 0x03020100u;
-        tr.kpz = nz ? kmz : kpz; tr.kmz = nz ? kpz : kmz; tr.selz = nz ? 0x01000302u : 0x03020100u;
+        // LDS nodes: a ray along +axis enters a box through lo and leaves through hi, one along -axis the other way round, so
+        // {near, far} = {lo, hi} or {hi, lo} by the sign of 1/d alone -- chosen by one byte permute of the {lo, hi} dword instead of
+        // a v_min / v_max pair per plane pair -- and with the box inflated by rho:  t_near = (near - o) / d - rho / |d|,
+        // t_far = (far - o) / d + rho / |d|,  i.e. fma(plane, 1/d, -o/d -+ rho/|d|): no sign-dependent select in the constants either.
+        const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+        const float rx = rho * fabsf(ix), ry = rho * fabsf(iy), rz = rho * fabsf(iz);
+        tr.kpx = ox - rx; tr.kpy = oy - ry; tr.kpz = oz - rz;
+        tr.kmx = ox + rx; tr.kmy = oy + ry; tr.kmz = oz + rz;
+        const uint32_t ID = 0x03020100u, FLIP = 0x03020100u ^ 0x01000302u;      // selector XOR mask: all ones where 1/d < 0
+        tr.selx = ID ^ ((uint32_t)((int32_t)__float_as_uint(ix) >> 31) & FLIP);
+        tr.sely = ID ^ ((uint32_t)((int32_t)__float_as_uint(iy) >> 31) & FLIP);
+        tr.selz = ID ^ ((uint32_t)((int32_t)__float_as_uint(iz) >> 31) & FLIP);
     } else {
-        tr.kpx = kpx; tr.kpy = kpy; tr.kpz = kpz; tr.kmx = kmx; tr.kmy = kmy; tr.kmz = kmz;
+        // t(lo) = (lo - rho - o) * inv = fma(lo, inv, -(o + rho) * inv);  t(hi) = fma(hi, inv, -(o - rho) * inv)
+        tr.kpx = -(o.x + rho) * ix; tr.kpy = -(o.y + rho) * iy; tr.kpz = -(o.z + rho) * iz;
+        tr.kmx = -(o.x - rho) * ix; tr.kmy = -(o.y - rho) * iy; tr.kmz = -(o.z - rho) * iz;
     }
     tr.lo_lim = A.mint - tr.tau_t;
     tr.hi_lim = tr.best_t + tr.tau_t;
