@@ -428,7 +428,7 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 // rho/tau small and gives an early best_t.
 #define RTW_KU 1.4305115e-6f    /* 24 * 2^-24 */
 #ifndef RTW_S_HI
-#define RTW_S_HI 56u            /* lanes waiting in SHADE that trigger a SHADE step (48: 26.93, 56: 27.08, 60/64: 26.94 Gsegments/s) */
+#define RTW_S_HI 48u            /* lanes waiting in SHADE that trigger a SHADE step (bench frame 48: 26.93, 56: 27.08, 60/64: 26.94 Gsegments/s; the dielectric-heavy C4 frame loses 3 % at 56) */
 #endif
 #ifndef RTW_TRAV_UNROLL
 #define RTW_TRAV_UNROLL 3       /* node visits per scheduling decision (1: 13.2, 2: 14.4, 3: 14.9, 4: 14.2 Gsegments/s) */
