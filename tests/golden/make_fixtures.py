@@ -16,7 +16,9 @@ committed so that the GPU box and later rounds never need the reference tree.
                                                a light, a smoke box, a glass pane, ray_color_bg_color
                         Rust/First frame.png   main()'s seven spheres (main.rs:427-545): 100 spp, depth 100
                       Both were rendered with the reference's unseeded ThreadRng, so they pin the restatement
-                      statistically (block means), not bit for bit.
+                      statistically (block means), not bit for bit.  Plus, verbatim, Rust/test.png (256x256), the
+                      image the reference's writer test saves (write_img.rs:33-58): an exact golden for the 8-bit
+                      quantiser.
 """
 import ctypes as C
 import hashlib
@@ -89,6 +91,12 @@ def ref_images():
         out[key + "_blocks16"] = img.reshape(h // 16, 16, w // 16, 16, 3).mean(axis=(1, 3)).astype(np.float32)
         out[key + "_black_pixels"] = np.array([(img.sum(axis=2) == 0).sum()])
         print(rel, "black pixels", int(out[key + "_black_pixels"][0]), "mean", img.mean(axis=(0, 1)))
+    # Rust/test.png: the output of the reference's own writer test (write_img.rs:33-58): pixel (i, j) = round(255 * (i/255, j/255, 0.25))
+    wt = np.asarray(Image.open(os.path.join(REF, "Rust/test.png")).convert("RGB")).astype(np.uint8)
+    assert wt.shape == (256, 256, 3)
+    # separable by construction (R depends on the column, G on the row, B is constant): store the three profiles
+    assert (wt[:, :, 0] == wt[0:1, :, 0]).all() and (wt[:, :, 1] == wt[:, 0:1, 1]).all() and (wt[:, :, 2] == wt[0, 0, 2]).all()
+    out["write_test_r_of_column"], out["write_test_g_of_row"], out["write_test_b"] = wt[0, :, 0].copy(), wt[:, 0, 1].copy(), wt[0, 0, 2:3].copy()
     np.savez_compressed(os.path.join(HERE, "ref_images.npz"), **out)
 
 

@@ -298,3 +298,21 @@ def test_python_scene_flattens_instances_into_pools():
     assert (i0.first_sphere, i0.n_spheres, i0.first_quad, i0.n_quads) == (0, 1, 0, 1)
     assert (i1.first_sphere, i1.n_spheres, i1.first_quad, i1.n_quads) == (1, 0, 1, 2)
     assert [q.origin[2] for q in list(sc._inst_quads)[:3]] == [0.0, 1.0, 2.0]
+
+
+def test_quantiser_against_the_reference_writer_test_image():
+    """Rust/test.png is what the reference's own writer test saves (write_img.rs:33-58): pixel (i, j) = (round(255 * i/255),
+    round(255 * j/255), round(255 * 0.25)) with f32 arithmetic.  rtw_quantize_u8 (== write_img_f32's rule, write_img.rs:11-15) and
+    the PNG writer must reproduce it exactly."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_images.npz"))
+    gold = np.empty((256, 256, 3), np.uint8)            # the fixture stores the image's three separable profiles
+    gold[:, :, 0] = z["write_test_r_of_column"][None, :]
+    gold[:, :, 1] = z["write_test_g_of_row"][:, None]
+    gold[:, :, 2] = z["write_test_b"][0]
+    i = np.arange(256, dtype=np.float32) / np.float32(255)
+    img = np.empty((256, 256, 3), np.float32)
+    img[:, :, 0] = i[None, :]
+    img[:, :, 1] = i[:, None]
+    img[:, :, 2] = np.float32(0.25)
+    assert np.array_equal(R.quantize_u8(img), gold)
