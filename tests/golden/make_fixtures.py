@@ -97,6 +97,9 @@ def ref_images():
     # separable by construction (R depends on the column, G on the row, B is constant): store the three profiles
     assert (wt[:, :, 0] == wt[0:1, :, 0]).all() and (wt[:, :, 1] == wt[:, 0:1, 1]).all() and (wt[:, :, 2] == wt[0, 0, 2]).all()
     out["write_test_r_of_column"], out["write_test_g_of_row"], out["write_test_b"] = wt[0, :, 0].copy(), wt[:, 0, 1].copy(), wt[0, 0, 2:3].copy()
+    # Rust/assets/squares.png (128 x 64, five flat colours): one of the image textures the reference's texture tests load
+    # (viewport/texture_test.rs); stored as the texel array ImageTexture::from_path would build (u8 / 255 per channel).
+    out["squares_png_rgb"] = np.asarray(Image.open(os.path.join(REF, "Rust/assets/squares.png")).convert("RGB")).astype(np.uint8)
     np.savez_compressed(os.path.join(HERE, "ref_images.npz"), **out)
 
 

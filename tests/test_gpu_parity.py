@@ -583,3 +583,27 @@ def test_bvh_equals_brute_force_on_adversarial_scenes(gpu, kind):
         assert st.segments == st_ref.segments, (kind, accel)
         assert np.array_equal(img, ref), (kind, accel, int((img != ref).any(axis=2).sum()))
     assert out[R.ACCEL_BVH][1].node_tests > 0
+
+
+def test_reference_texture_reflection_scene(gpu):
+    """reflection_test of Rust/src/viewport/texture_test.rs:87-138 -- a mirror sphere in front of a huge image-textured mirror
+    sphere, 400 x 300, 100 spp (stratified), depth 10 -- with the reference's own asset Rust/assets/squares.png as the image
+    (its earthmap.jpg is 1.5 MB; texels as ImageTexture::from_path builds them: u8 / 255).  The texel choice goes through
+    atan2f / acosf, so a texel edge may fall differently between glibc and ocml: a handful of pixels, nothing else."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_images.npz"))
+    tex = z["squares_png_rgb"].astype(np.float32) / np.float32(255.0)            # [64][128][3]
+    assert tex.shape == (64, 128, 3)
+    spheres = [R.Sphere.new((0.520, 0.0, -1.0), 0.45, (0.95, 0.95, 0.95), R.METALLIC_M),
+               R.Sphere.new_with_texture((-1001.0, 0.0, 0.0), 1000.0, None, R.METALLIC_M, 0)]
+    scene = R.Scene(spheres, textures=[tex])
+    vp = R.Viewport.new_from_res(400, 300, 100, 10, 2.0, vfov=90.0, origin=(0.0, 0.0, 0.0))
+    vp.maxt = 1000.0
+    cam = vp.camera()
+    p = vp.params(R.INTEGRATOR_GRADIENT, R.SAMPLER_STRATIFIED)
+    ref, st_ref, out = render_both(gpu, scene, cam, p)
+    assert len(np.unique(np.round(ref.reshape(-1, 3), 2), axis=0)) > 50        # the textured wall and its reflection are in view
+    for accel, (img, st) in out.items():
+        assert st.segments == st_ref.segments
+        same = (ulp_diff(img, ref) <= 2).all(axis=2)
+        assert same.mean() > 0.999, (accel, same.mean())
+    assert np.array_equal(out[R.ACCEL_BRUTE][0], out[R.ACCEL_BVH][0])
