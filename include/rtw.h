@@ -232,6 +232,13 @@ int  rtw_ctx_set_scene(rtw_ctx *ctx, const RtwScene *scene, float t_begin, float
  * unclamped (viewport.rs:301); it may be host memory or device memory of ctx's GPU. */
 int  rtw_ctx_render(rtw_ctx *ctx, const RtwCamera *cam, const RtwParams *params,
                     float *out_rgb, RtwStats *stats);
+/* == render_multi(viewport, ray_color, scene) -> Vec<Img> (Rust/src/viewport.rs:249-269): frames start_frame .. start_frame +
+ * n_frames, frame i rendered like async_render with time0 = i as f32 / fps (viewport.rs:279; cam->time0 is ignored, cam->shutter
+ * is the shutter_speed).  out_rgb holds n_frames images of [rows][width][3] f32 back to back (host or device memory); stats, if not
+ * NULL, is an array of n_frames.  The scene must have been set for the whole clip:
+ * rtw_ctx_set_scene(ctx, scene, start_frame / fps, (start_frame + n_frames - 1) / fps + shutter). */
+int  rtw_ctx_render_multi(rtw_ctx *ctx, const RtwCamera *cam, const RtwParams *params, float fps,
+                          uint32_t start_frame, uint32_t n_frames, float *out_rgb, RtwStats *stats);
 /* One-shot convenience: create ctx on the current device, set scene, render, destroy. */
 int  rtw_render(const RtwCamera *cam, const RtwScene *scene, const RtwParams *params,
                 float *out_rgb, RtwStats *stats);

@@ -134,6 +134,8 @@ def lib() -> C.CDLL:
     L.rtw_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.rtw_ctx_set_scene.argtypes = [C.c_void_p, C.POINTER(RtwScene), C.c_float, C.c_float]
     L.rtw_ctx_render.argtypes = [C.c_void_p, C.POINTER(RtwCamera), C.POINTER(RtwParams), C.c_void_p, C.POINTER(RtwStats)]
+    L.rtw_ctx_render_multi.argtypes = [C.c_void_p, C.POINTER(RtwCamera), C.POINTER(RtwParams), C.c_float, C.c_uint32, C.c_uint32,
+                                       C.c_void_p, C.POINTER(RtwStats)]
     L.rtw_render.argtypes = [C.POINTER(RtwCamera), C.POINTER(RtwScene), C.POINTER(RtwParams), C.c_void_p, C.POINTER(RtwStats)]
     L.rtw_viewport_new.argtypes = [C.c_uint32, C.c_float, fp, fp, fp, fp, fp, C.POINTER(RtwCamera), C.POINTER(C.c_uint32)]
     L.rtw_viewport_new_from_res.argtypes = [C.c_uint32, C.c_uint32, fp, fp, fp, fp, fp, C.POINTER(RtwCamera), C.POINTER(C.c_uint32)]
@@ -467,15 +469,18 @@ class Viewport:
         with time = frame / fps (the scene and its time-expanded BVH are uploaded once for the whole clip)."""
         start = getattr(self, "start_frame", 0)
         count = getattr(self, "number_of_frames", 1)
-        video = []
         with Renderer(device) as r:
             t0 = float(np.float32(start) / np.float32(self.fps))
             t1 = float(np.float32(start + max(count, 1) - 1) / np.float32(self.fps)) + float(self.shutter_speed)
             r.set_scene(scene, t0, t1)
-            for frame in range(start, start + count):
-                self.frame = frame
-                video.append(r.render(self.camera(), self.params(ray_color, SAMPLER_ROW, accel))[0])
-        return video
+            p = self.params(ray_color, SAMPLER_ROW, accel)
+            video = np.empty((max(count, 0), self.height, self.width, 3), np.float32)
+            st = (RtwStats * max(count, 1))()
+            cam = self.camera()
+            _check(lib().rtw_ctx_render_multi(r._h, C.byref(cam), C.byref(p), float(self.fps), int(start), int(count),
+                                              C.c_void_p(video.ctypes.data), st), "rtw_ctx_render_multi")
+        self.frame = start + max(count, 1) - 1
+        return [video[i] for i in range(count)]
 
     def render_no_rand(self, ray_color: int, scene: Scene, device: int = 0, accel: int = ACCEL_BVH) -> np.ndarray:
         return self._render(ray_color, SAMPLER_NO_RAND, scene, device, accel)

@@ -418,6 +418,19 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     return RTW_OK;
 }
 
+int rtw_ctx_render_multi(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float fps, uint32_t start_frame, uint32_t n_frames,
+                         float *out_rgb, RtwStats *stats) {
+    if (!c || !cam || !p || !out_rgb || !(fps > 0.0f)) return RTW_E_INVALID;
+    const size_t frame_floats = (size_t)rtw_part_rows(p->height, p->row_block, p->part_index, p->part_count) * p->width * 3;
+    for (uint32_t i = 0; i < n_frames; i++) {                     // viewport.rs:256-266, one async_render per frame
+        RtwCamera cm = *cam;
+        cm.time0 = host_div((float)(start_frame + i), fps);       // viewport.rs:279  frame as f32 / fps
+        int rc = rtw_ctx_render(c, &cm, p, out_rgb + (size_t)i * frame_floats, stats ? stats + i : nullptr);
+        if (rc != RTW_OK) return rc;
+    }
+    return RTW_OK;
+}
+
 int rtw_render(const RtwCamera *cam, const RtwScene *scene, const RtwParams *params, float *out_rgb, RtwStats *stats) {
     if (!cam || !scene || !params) return RTW_E_INVALID;
     int dev = 0;
