@@ -52,6 +52,8 @@ extern "C" {
     fn rtw_ctx_destroy(ctx: *mut RtwCtx);
     fn rtw_ctx_set_scene(ctx: *mut RtwCtx, scene: *const RtwScene, t_begin: f32, t_end: f32) -> i32;
     fn rtw_ctx_render(ctx: *mut RtwCtx, cam: *const RtwCamera, p: *const RtwParams, out_rgb: *mut c_void, st: *mut RtwStats) -> i32;
+    fn rtw_ctx_render_multi(ctx: *mut RtwCtx, cam: *const RtwCamera, p: *const RtwParams, fps: f32, start_frame: u32, n_frames: u32,
+                            out_rgb: *mut c_void, st: *mut RtwStats) -> i32;
     fn rtw_strerror(status: i32) -> *const std::os::raw::c_char;
 }
 
@@ -102,6 +104,16 @@ impl Renderer {
         check(unsafe { rtw_ctx_render(self.ctx, cam, p, flat.as_mut_ptr() as *mut c_void, &mut st) })?;
         let rows = flat.chunks(p.width as usize).take(st.rows as usize).map(|r| r.to_vec()).collect();
         Ok((rows, st))
+    }
+}
+impl Renderer {
+    /// == `render_multi` (viewport.rs:249-269): frames start_frame .. start_frame + n_frames at time frame / fps.
+    pub fn render_multi(&mut self, cam: &RtwCamera, p: &RtwParams, fps: f32, start_frame: u32, n_frames: u32)
+        -> Result<Vec<Vec<Vec<[f32; 3]>>>, RtwError> {
+        let per = (p.width as usize) * (p.height as usize);
+        let mut flat = vec![[0f32; 3]; per * n_frames as usize];
+        check(unsafe { rtw_ctx_render_multi(self.ctx, cam, p, fps, start_frame, n_frames, flat.as_mut_ptr() as *mut c_void, std::ptr::null_mut()) })?;
+        Ok(flat.chunks(per).map(|f| f.chunks(p.width as usize).map(|r| r.to_vec()).collect()).collect())
     }
 }
 impl Drop for Renderer { fn drop(&mut self) { unsafe { rtw_ctx_destroy(self.ctx) } } }
