@@ -654,6 +654,9 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     unsigned long long c_time[3] = { 0, 0, 0 };
 #endif
 
+#ifdef RTW_ENDTIMES
+    const unsigned long long t_wave_start = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         // ---- scheduler ---------------------------------------------------------------------------
         // SHADE is the expensive step (several hundred instructions): it runs when enough lanes have piled up
@@ -741,6 +744,13 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[5 + k], (unsigned long long)c_steps[k]); atomicAdd(&A.stats[8 + k], (unsigned long long)c_lanes[k]); }
 #ifdef RTW_STAMP
         for (int k = 0; k < 3; k++) atomicAdd(&A.stats[11 + k], c_time[k]);
+#endif
+#ifdef RTW_ENDTIMES
+        // diagnostic build only: when do the waves of a launch start and finish?  (overwrites the census slots)
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        atomicMax(&A.stats[12], t_end - t_wave_start);     // longest wave lifetime (s_memtime is per XCD: only differences within a wave mean anything)
+        atomicAdd(&A.stats[13], t_end - t_wave_start);     // sum of the waves' lifetimes
+        atomicAdd(&A.stats[15], 1ull);                     // waves
 #endif
     }
 }

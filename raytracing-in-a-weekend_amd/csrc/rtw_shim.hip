@@ -413,6 +413,10 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
         stats->kernel_ms = ms;
         for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
         if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu\n", h_stats[11], h_stats[12], h_stats[13]);
+        if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15]) {   // RTW_ENDTIMES build: [12] longest wave lifetime [13] sum of wave lifetimes [15] waves
+            std::fprintf(stderr, "rtw endtimes: %llu waves, longest lifetime %llu ticks, mean lifetime %.1f %% of it\n", h_stats[15], h_stats[12],
+                         100.0 * (double)h_stats[13] / (double)h_stats[15] / (double)h_stats[12]);
+        }
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return RTW_OK;

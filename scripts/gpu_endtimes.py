@@ -1,0 +1,14 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+import rtw_amd as R
+scene = R.Scene.generate(R.SCENE_C2, 42)
+cam, p = R.default_view(R.SCENE_C5); cam.shutter = 0.0
+r = R.Renderer(0); r.set_scene(scene)
+out = torch.zeros((1080, 1920, 3), dtype=torch.float32, device="cuda:0")
+for n in (1, 8, 64):
+    p.row_block, p.part_index, p.part_count = 8, n // 2, n
+    r.render(cam, p, out=out.data_ptr())
+    sys.stderr.write(f"--- 1/{n} of the rows\n"); sys.stderr.flush()
+    _, st = r.render(cam, p, out=out.data_ptr())
+    sys.stderr.write(f"    kernel {st.kernel_ms:.3f} ms\n")
