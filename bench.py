@@ -78,8 +78,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-nodes", action="store_true", help="A/B: BVH nodes in global memory (f32) instead of LDS (f16)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (INVALID as a benchmark; for smoke runs)")
+    ap.add_argument("--devices", default="", help="single-process rtw_mgpu over these HIP ordinals, e.g. 0,0,0 = three contexts on one GPU "
+                                                  "(a rehearsal of the N-GPU path on a 1-GPU box: INVALID as a benchmark)")
     args = ap.parse_args()
 
+    # dmabuf IPC only on this pool: must be in the environment BEFORE anything initialises HIP / HSA (torch.cuda, librtw_hip)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import importlib
@@ -97,7 +101,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
         else:
@@ -113,19 +116,33 @@ def main():
         p.samples = args.spp
     H, W = p.height, p.width
 
-    r = R.Renderer(local_rank)                                  # one rtw_ctx per process == per GPU
-    r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
-    local = torch.zeros((par.max_rows(H, world), W, 3), dtype=torch.float32, device=dev)
+    single_process_multi = world == 1 and (args.gpus > 1 or bool(args.devices))   # one process drives all GPUs through the C ABI's rtw_mgpu
+    if single_process_multi:
+        devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        assert R.device_count() > max(devices), f"devices {devices} but only {R.device_count()} HIP devices are visible"
+        args.gpus = len(devices)
+        r = R.MultiRenderer(devices)              # fork / ordered join of viewport.rs:236-244 over GPUs, no torch.distributed
+        r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
+        frame_buf = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
 
-    def render_rows(row_block, idx, cnt, out):
-        q = R.RtwParams.from_buffer_copy(p)
-        q.row_block, q.part_index, q.part_count = row_block, idx, cnt
-        return r.render(cam, q, out=out.data_ptr())[1]
+        def step():
+            _, tot, _ = r.render(cam, p, out=frame_buf.data_ptr())     # every device copies its row blocks straight into GPU 0's frame
+            return frame_buf, tot
+    else:
+        r = R.Renderer(local_rank)                                  # one rtw_ctx per process == per GPU
+        r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
+        local = torch.zeros((par.max_rows(H, world), W, 3), dtype=torch.float32, device=dev)
 
-    def step():
-        frame, st = par.render_frame(render_rows, H, W, rank, world, dev, local=local)
-        return frame, st
+        def render_rows(row_block, idx, cnt, out):
+            q = R.RtwParams.from_buffer_copy(p)
+            q.row_block, q.part_index, q.part_count = row_block, idx, cnt
+            return r.render(cam, q, out=out.data_ptr())[1]
+
+        def step():
+            frame, st = par.render_frame(render_rows, H, W, rank, world, dev, local=local)
+            return frame, st
 
     def fence():
         if world > 1:
@@ -152,6 +169,8 @@ def main():
     seg, rays, nodes, tests = par.reduce_counters([seg, rays, nodes, tests], world, dev)
     kernel_ms_max = par.max_over_ranks(kernel_ms, world, dev)
 
+    if single_process_multi:
+        world = args.gpus                                           # per-GPU figures below divide by the GPUs that shared the frame
     if rank == 0:
         k_s = kernel_ms_max / 1e3 / args.steps                      # mean kernel time per launch (slowest rank)
         flop = (nodes * F_NODE + tests * F_SPHERE + seg * F_SEGMENT) / args.steps / world   # per launch, per GPU
@@ -169,7 +188,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: Book-1 final random-spheres scene (485 spheres, scene seed 42), "
                                    f"{W}x{H}, {p.samples} spp (render_row sampler), depth {p.depth}, gradient sky, render seed 1; "
-                                   "rows in interleaved 8-row blocks per GPU + one RCCL gather",
+                                   "rows in interleaved 8-row blocks per GPU + " +
+                                   ("rtw_mgpu (one process, strided peer copies into GPU 0's frame)" if single_process_multi else "one RCCL gather"),
                        "accel": args.accel, "camera_msamples_per_s": round(rays / elapsed / 1e6, 3),
                        "segments_per_camera_ray": round(seg / max(rays, 1), 4)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -191,7 +211,7 @@ def main():
         assert frame is not None and bool(torch.isfinite(frame).all())
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if world > 1 and not single_process_multi:
         dist.destroy_process_group()
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTW_ABI_VERSION 2
+#define RTW_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------- */
 #define RTW_OK              0
@@ -189,10 +189,24 @@ typedef struct RtwParams {
 
 #define RTW_FLAG_NONE            0u
 #define RTW_FLAG_RECURSIVE_ORDER 1u  /* oracle only: multiply col_mod in the reference's recursion order */
+#define RTW_FLAG_CPP_DIELECTRIC  2u  /* the C++ twin's deterministic dielectric (Schlick term commented out,
+                                        C++/headers/materials.h:106): refract whenever possible, no draw */
 #define RTW_FLAG_GLOBAL_NODES    4u  /* device only: keep the BVH nodes in global memory (f32, 64 B) even when the
                                         f16 LDS-resident copy is available -- for A/B measurements and tests */
-#define RTW_FLAG_CPP_DIELECTRIC  2u  /* oracle only: the C++ twin's deterministic dielectric (Schlick term
-                                        commented out, C++/headers/materials.h:106): refract whenever possible */
+#define RTW_FLAG_CPP_DIFFUSE     8u  /* the C++ twin's non-dielectric branch (C++/headers/materials.h:113-117,
+                                        C++/src/materials.cpp:4-13, C++/src/vec3.cpp:28-39, C++/src/sphere.cpp:29-31), in f32:
+                                        rejection accepts |p|^2 < 1 (not <= 1); the diffuse direction is
+                                        unit((point + normal + rand_unit) - point); the mirror direction is normalised again,
+                                        unit(reflect(unit(d), n)); a near-zero (1e-8) result becomes the normal.
+                                        RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE is what Viewport::RenderGPU of the C++
+                                        tree asks for. */
+#define RTW_FLAG_CHUNK_SUMS     16u  /* device only: a lane adds the samples of its work unit (RTW_OPT_CHUNK_LEN consecutive samples
+                                        of one pixel) in registers and banks ONE partial sum per unit; the resolve pass adds the
+                                        partial sums in chunk order.  Deterministic and independent of the GPU split like the default,
+                                        but the f32 summation is associated per chunk, ((s0+s1+s2+s3) + (s4+..)) + .., instead of the
+                                        reference's left-to-right order (viewport.rs:299): the image differs by rounding only
+                                        (<= 1e-6 relative, inside BASELINE.json's 1e-3), and the bank shrinks by chunk_len
+                                        (12.4 GB -> 3.1 GB at 1920x1080x500). */
 
 typedef struct RtwStats {
     uint64_t camera_rays;    /* (pixel, sample) primary rays traced                   */
@@ -226,7 +240,9 @@ void rtw_ctx_destroy(rtw_ctx *ctx);
 int  rtw_ctx_set_stream(rtw_ctx *ctx, void *hip_stream);
 /* == Scene::new_sphere(spheres) (viewport.rs:90-105): copies the scene to the GPU and builds the
  * acceleration structure.  [t_begin, t_end] is the ray.time range the bounds must cover
- * (time0 .. time0 + shutter); pass 0,0 for static scenes. */
+ * (time0 .. time0 + shutter); pass 0,0 for static scenes.  The range is remembered: a later render of a
+ * MOVING scene whose [time0, time0 + shutter] is not inside it walks the list instead of the tree (same image,
+ * slower) rather than pruning with bounds that do not cover the spheres. */
 int  rtw_ctx_set_scene(rtw_ctx *ctx, const RtwScene *scene, float t_begin, float t_end);
 /* == Viewport::render(ray_color, scene) -> Img.  out_rgb is [rows][width][3] f32, gamma-corrected,
  * unclamped (viewport.rs:301); it may be host memory or device memory of ctx's GPU. */
@@ -242,6 +258,41 @@ int  rtw_ctx_render_multi(rtw_ctx *ctx, const RtwCamera *cam, const RtwParams *p
 /* One-shot convenience: create ctx on the current device, set scene, render, destroy. */
 int  rtw_render(const RtwCamera *cam, const RtwScene *scene, const RtwParams *params,
                 float *out_rgb, RtwStats *stats);
+
+/* Tuning knobs of a context (they were process environment variables up to ABI v2).  None of them changes the image. */
+enum {
+    RTW_OPT_CHUNK_LEN        = 1, /* samples per work unit, 1..4096 (default 4)                                          */
+    RTW_OPT_SAMPLE_BANK_GB   = 2, /* budget of the per-sample radiance bank in GiB (default 48); larger frames are
+                                     rendered in bands of tile rows, a budget below one tile row fails with RTW_E_NOMEM  */
+    RTW_OPT_LDS_GEOM         = 3, /* sphere {centre, r^2} in LDS next to the f16 nodes: -1 auto (default), 0 off, 1 on   */
+    RTW_OPT_BLOCKS_PER_CU    = 4, /* resident workgroups per CU of the persistent grid: 0 auto (default), 1..8           */
+    RTW_OPT_LIST_WALK_MAX    = 5  /* RTW_ACCEL_BVH requests for scenes with at most this many spheres walk the list
+                                     instead (result-invariant; the traversal scheduler only costs there).  Default:
+                                     the measured crossover; 0 = always use the tree                     */
+};
+int  rtw_ctx_set_option(rtw_ctx *ctx, uint32_t key, double value);
+
+/* ---- one frame over several GPUs of a node ------------------------------------------------------
+ * The reference forks one task per image row and joins them in order (tokio: Rust/src/viewport.rs:236-244; rayon:
+ * Rust2/src/viewport.rs:119-122).  Here the rows are dealt to the devices in interleaved blocks of `row_block` rows
+ * (RtwParams.row_block, 8 when 0; device k renders the rows r with (r / row_block) % n_devices == k) and every device
+ * copies its blocks STRAIGHT INTO their image rows of the caller's frame (one strided 2-D copy per device, no gather
+ * buffer, no de-interleave pass).  The counter-based RNG makes the image independent of the split: the result is bit-identical
+ * to rtw_ctx_render of the whole frame on one GPU.  One host thread drives all devices (launches are asynchronous); the call
+ * blocks until the frame is complete.  `devices` are HIP ordinals and may repeat (several contexts on one GPU).
+ * out_rgb: the full [height][width][3] f32 frame, host memory or device memory of any of the GPUs.
+ * params->part_count must be <= 1.  per_device (may be NULL): n_devices RtwStats; total (may be NULL): counters summed,
+ * kernel_ms = the slowest device, total_ms = host wall time of the call. */
+typedef struct rtw_mgpu rtw_mgpu;
+int  rtw_mgpu_create(const int *devices, uint32_t n_devices, rtw_mgpu **out);
+void rtw_mgpu_destroy(rtw_mgpu *m);
+int  rtw_mgpu_set_scene(rtw_mgpu *m, const RtwScene *scene, float t_begin, float t_end);
+int  rtw_mgpu_set_option(rtw_mgpu *m, uint32_t key, double value);
+int  rtw_mgpu_render(rtw_mgpu *m, const RtwCamera *cam, const RtwParams *params, float *out_rgb,
+                     RtwStats *per_device, RtwStats *total);
+/* One-shot: create, set scene for [cam->time0, cam->time0 + cam->shutter], render, destroy. */
+int  rtw_render_multi_gpu(const int *devices, uint32_t n_devices, const RtwCamera *cam, const RtwScene *scene,
+                          const RtwParams *params, float *out_rgb, RtwStats *per_device);
 
 /* ---- host mirror of the reference constructors (same library, no GPU needed) ---------------- */
 
@@ -272,6 +323,10 @@ int rtw_quad_new(const float origin[3], const float u[3], const float v[3], cons
 /* Instance::new_box(a, b, tex, mat) (instance.rs:83-176): the six quads of the axis-aligned box, in the
  * reference's order, written to quads6[0..6). */
 int rtw_box_quads(const float a[3], const float b[3], const float *mat3, const float color[3], RtwQuad quads6[6]);
+/* Vec3::rotated(rot) (Rust/src/vec3.rs:161-181) as the library applies it to instances: sin / cos of the three angles on the
+ * host, the products in the reference's written order (including its non-orthogonal terms for rotations about more than
+ * one axis). */
+void rtw_vec3_rotated(const float v[3], const float rot[3], float out[3]);
 /* Rows a partition owns (see RtwParams). */
 uint32_t rtw_part_rows(uint32_t height, uint32_t row_block, uint32_t part_index, uint32_t part_count);
 /* write_img_f32 quantisation: round(clamp(c*255, 0, 255)) (Rust/src/write_img.rs:11-15). */

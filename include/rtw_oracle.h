@@ -58,6 +58,9 @@ float rtw_oracle_rng_next(uint32_t state[2]);
 float rtw_oracle_ln(float x);
 void  rtw_oracle_ln_bulk(const float *x, float *out, size_t n);
 
+/* Vec3::rotated (Rust/src/vec3.rs:161-181), for the reference's rotation_tests known answers (vec3.rs:363-404). */
+void  rtw_oracle_rotated(const float v[3], const float rot[3], float out[3]);
+
 #ifdef __cplusplus
 }
 #endif

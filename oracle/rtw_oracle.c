@@ -116,21 +116,25 @@ static inline v3 random_vec(rng_t *r, float min, float max) {
     p.z = rng_f32(r) * (max - min) + min;
     return p;
 }
-/* vec3.rs:228-239  rejection in the cube, accept len2 <= 1, then unit() */
-static inline v3 random_unit_vec(rng_t *r) {
+/* vec3.rs:228-239  rejection in the cube, accept len2 <= 1, then unit().
+ * strict (RTW_FLAG_CPP_DIFFUSE): the C++ twin rejects len2 >= 1 (C++/src/vec3.cpp:28-34) */
+static inline v3 random_unit_vec_s(rng_t *r, int strict) {
     for (;;) {
         v3 p = random_vec(r, -1.0f, 1.0f);
-        if (p.x * p.x + p.y * p.y + p.z * p.z <= 1.0f) return v3_unit(p);
+        float l2 = p.x * p.x + p.y * p.y + p.z * p.z;
+        if (strict ? l2 < 1.0f : l2 <= 1.0f) return v3_unit(p);
     }
 }
-/* vec3.rs:240-254  (2 xi - 1, 2 xi - 1, 0), accept len2 <= 1 */
-static inline v3 random_in_unit_disk(rng_t *r) {
+static inline v3 random_unit_vec(rng_t *r) { return random_unit_vec_s(r, 0); }
+/* vec3.rs:240-254  (2 xi - 1, 2 xi - 1, 0), accept len2 <= 1  (C++/headers/vec3.h:35-41: < 1) */
+static inline v3 random_in_unit_disk_s(rng_t *r, int strict) {
     for (;;) {
         v3 p;
         p.x = rng_f32(r) * 2.0f - 1.0f;
         p.y = rng_f32(r) * 2.0f - 1.0f;
         p.z = 0.0f;
-        if (p.x * p.x + p.y * p.y <= 1.0f) return p;
+        float l2 = p.x * p.x + p.y * p.y;
+        if (strict ? l2 < 1.0f : l2 <= 1.0f) return p;
     }
 }
 
@@ -297,6 +301,12 @@ static inline v3 v3_rotated(v3 a, rot_t q) {
     return o;
 }
 
+/* Vec3::rotated exposed for the reference's own known answers (vec3.rs:363-404 rotation_tests) */
+void rtw_oracle_rotated(const float v[3], const float rot[3], float out[3]) {
+    v3 r = v3_rotated(v3_ld(v), rot_make(v3_ld(rot)));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
 /* ln(x) for a positive normal f32, computed in f64 (atanh series of (m-1)/(m+1), 12 terms) and rounded once:
  * the correctly rounded result for every xi = k * 2^-24 the RNG can produce (checked exhaustively against logl
  * in tests/test_oracle_golden.py).  Written out instead of calling libm so that the device, which evaluates
@@ -398,7 +408,7 @@ static inline float reflectance(float cosine, float ref_idx) {
     return r0 + (1.0f - r0) * x5;
 }
 
-typedef struct { ray_t next; v3 emitted; float cos_theta; int front_face, cannot_refract; float ratio; } scatter_t;
+typedef struct { ray_t next; v3 emitted; float cos_theta; int front_face, cannot_refract; float ratio; int cpp_fixed; } scatter_t;
 
 /* materials.rs:105-154 (+ diffuse :213-228) */
 static scatter_t on_hit(const mat_t *s, const hit_t *h, ray_t r, rng_t *rng, uint32_t flags) {
@@ -424,6 +434,20 @@ static scatter_t on_hit(const mat_t *s, const hit_t *h, ray_t r, rng_t *rng, uin
         o.cos_theta = 0.0f; o.cannot_refract = cannot_refract; o.ratio = refraction_ratio;
         return o;
     }
+    if (flags & RTW_FLAG_CPP_DIFFUSE) {
+        /* the C++ twin, in f32 (C++/headers/materials.h:113-117, C++/src/materials.cpp:4-13, C++/src/sphere.cpp:29-31):
+         *   sc = unit((point + normal + random_unit_vec()) - point) * (1 - m);  reflect = unit(reflect(unit(d), n));
+         *   direction = reflect * m + sc;  near_zero (1e-8) -> normal.  cpp_fixed tells fix_degenerate to keep its hands off. */
+        v3 target = v3_add(v3_add(h->point, h->normal), random_unit_vec_s(rng, 1));
+        v3 sdir = v3_unit(v3_sub(target, h->point));
+        v3 mdir = v3_unit(v3_reflect(v3_unit(r.dir), h->normal));
+        v3 dir = v3_add(v3_scale(mdir, s->metallicness), v3_scale(sdir, 1.0f - s->metallicness));
+        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = h->normal;
+        o.next.origin = h->point; o.next.dir = dir; o.next.time = r.time;
+        o.cos_theta = (s->metallicness != 1.0f) ? v3_dot(sdir, h->normal) : 0.0f;
+        o.cpp_fixed = 1;
+        return o;
+    }
     /* diffuse(): drawn even for metallicness == 1 (materials.rs:142) */
     v3 target = v3_add(h->normal, random_unit_vec(rng));
     v3 sc = v3_close_to_zero(target) ? h->normal : target;
@@ -436,6 +460,7 @@ static scatter_t on_hit(const mat_t *s, const hit_t *h, ray_t r, rng_t *rng, uin
 
 /* ray_color.rs:31-33 */
 static inline void fix_degenerate(scatter_t *s, const hit_t *h) {
+    if (s->cpp_fixed) return;                       /* the C++ branch applied its own near_zero rule */
     if (v3_close_to_zero(s->next.dir)) s->next.dir = s->front_face ? h->normal : v3_scale(h->normal, -1.0f);
 }
 
@@ -697,7 +722,7 @@ static void render_pixel(const RtwCamera *cam, const RtwScene *sc, const RtwPara
         rng_t rng = rng_seed(p->seed, pixel, s); c.rng = &rng;
         ray_t r;
         if (p->sampler == RTW_SAMPLER_ROW) {                        /* viewport.rs:287-299 */
-            v3 rp = random_in_unit_disk(&rng);
+            v3 rp = random_in_unit_disk_s(&rng, (p->flags & RTW_FLAG_CPP_DIFFUSE) != 0);
             r.origin = v3_add(origin, v3_scale(v3_add(v3_scale(cu, rp.x), v3_scale(cv, rp.y)), cam->lens_radius));
             float jx = (float)i + rng_f32(&rng);
             float jy = (float)j + rng_f32(&rng);
@@ -705,7 +730,7 @@ static void render_pixel(const RtwCamera *cam, const RtwScene *sc, const RtwPara
             r.time = cam->time0 + cam->shutter * rng_f32(&rng);
         } else if (p->sampler == RTW_SAMPLER_STRATIFIED) {          /* viewport.rs:452-470: x outer, y inner */
             uint32_t x = s / s_root, y = s % s_root;
-            v3 rp = random_in_unit_disk(&rng);
+            v3 rp = random_in_unit_disk_s(&rng, (p->flags & RTW_FLAG_CPP_DIFFUSE) != 0);
             r.origin = v3_add(origin, v3_scale(v3_add(v3_scale(cu, rp.x), v3_scale(cv, rp.y)), cam->lens_radius));
             float jx = (float)i + (((float)x + rng_f32(&rng)) / (float)s_root);
             float jy = (float)j + (((float)y + rng_f32(&rng)) / (float)s_root);
@@ -713,7 +738,7 @@ static void render_pixel(const RtwCamera *cam, const RtwScene *sc, const RtwPara
             r.time = 0.0f;                                          /* Ray::new */
         } else {                                                    /* Rust2/src/viewport.rs:92-104: k outer (x), l inner (y) */
             uint32_t k = s / s_root, l = s % s_root;
-            v3 rp = random_in_unit_disk(&rng);
+            v3 rp = random_in_unit_disk_s(&rng, (p->flags & RTW_FLAG_CPP_DIFFUSE) != 0);
             /* Rust2 offsets the origin by the raw disk point * lens_radius (not in the u,v basis) */
             r.origin = v3_add(origin, v3_scale(rp, cam->lens_radius));
             /* here pixel00/delta_u/delta_v hold Rust2's left_top and FULL-viewport delta_x/delta_y

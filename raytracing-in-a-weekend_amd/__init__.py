@@ -35,7 +35,9 @@ RTW_OK = 0
 INTEGRATOR_GRADIENT, INTEGRATOR_BG_COLOR, INTEGRATOR_NORMAL, INTEGRATOR_FLAG, INTEGRATOR_RUST2 = 0, 1, 2, 3, 4
 SAMPLER_ROW, SAMPLER_STRATIFIED, SAMPLER_CENTRES, SAMPLER_NO_RAND = 0, 1, 2, 3
 ACCEL_BRUTE, ACCEL_BVH = 0, 1
-FLAG_RECURSIVE_ORDER, FLAG_CPP_DIELECTRIC, FLAG_GLOBAL_NODES = 1, 2, 4
+FLAG_RECURSIVE_ORDER, FLAG_CPP_DIELECTRIC, FLAG_GLOBAL_NODES, FLAG_CPP_DIFFUSE, FLAG_CHUNK_SUMS = 1, 2, 4, 8, 16
+FLAG_CPP = FLAG_CPP_DIELECTRIC | FLAG_CPP_DIFFUSE      # what Viewport::RenderGPU of the C++ tree asks for
+OPT_CHUNK_LEN, OPT_SAMPLE_BANK_GB, OPT_LDS_GEOM, OPT_BLOCKS_PER_CU, OPT_LIST_WALK_MAX = 1, 2, 3, 4, 5
 SCENE_C1, SCENE_C2, SCENE_C4, SCENE_C5, SCENE_METAL_TEST, SCENE_QUAD_TEST, SCENE_PRESENTATION, SCENE_FIRST_FRAME = 1, 2, 4, 5, 6, 7, 8, 9
 MEDIUM_SURFACE, MEDIUM_CONST_DENSITY = 0, 1
 
@@ -137,10 +139,21 @@ def lib() -> C.CDLL:
     L.rtw_ctx_render_multi.argtypes = [C.c_void_p, C.POINTER(RtwCamera), C.POINTER(RtwParams), C.c_float, C.c_uint32, C.c_uint32,
                                        C.c_void_p, C.POINTER(RtwStats)]
     L.rtw_render.argtypes = [C.POINTER(RtwCamera), C.POINTER(RtwScene), C.POINTER(RtwParams), C.c_void_p, C.POINTER(RtwStats)]
+    L.rtw_ctx_set_option.argtypes = [C.c_void_p, C.c_uint32, C.c_double]
+    L.rtw_mgpu_create.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.rtw_mgpu_destroy.argtypes = [C.c_void_p]
+    L.rtw_mgpu_destroy.restype = None
+    L.rtw_mgpu_set_scene.argtypes = [C.c_void_p, C.POINTER(RtwScene), C.c_float, C.c_float]
+    L.rtw_mgpu_set_option.argtypes = [C.c_void_p, C.c_uint32, C.c_double]
+    L.rtw_mgpu_render.argtypes = [C.c_void_p, C.POINTER(RtwCamera), C.POINTER(RtwParams), C.c_void_p, C.POINTER(RtwStats), C.POINTER(RtwStats)]
+    L.rtw_render_multi_gpu.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(RtwCamera), C.POINTER(RtwScene), C.POINTER(RtwParams),
+                                       C.c_void_p, C.POINTER(RtwStats)]
     L.rtw_viewport_new.argtypes = [C.c_uint32, C.c_float, fp, fp, fp, fp, fp, C.POINTER(RtwCamera), C.POINTER(C.c_uint32)]
     L.rtw_viewport_new_from_res.argtypes = [C.c_uint32, C.c_uint32, fp, fp, fp, fp, fp, C.POINTER(RtwCamera), C.POINTER(C.c_uint32)]
     L.rtw_sphere_new.argtypes = [fp, C.c_float, fp, fp, fp, C.POINTER(RtwSphere)]
     L.rtw_sphere_new_with_texture.argtypes = [fp, C.c_float, fp, fp, fp, C.c_int32, C.POINTER(RtwSphere)]
+    L.rtw_vec3_rotated.restype = None
+    L.rtw_vec3_rotated.argtypes = [fp, fp, fp]
     L.rtw_part_rows.restype = C.c_uint32
     L.rtw_part_rows.argtypes = [C.c_uint32] * 4
     L.rtw_quantize_u8.restype = None
@@ -525,6 +538,10 @@ class Renderer:
         self._scene = scene     # keep host arrays alive
         _check(lib().rtw_ctx_set_scene(self._h, C.byref(scene.pod), float(t_begin), float(t_end)), "rtw_ctx_set_scene")
 
+    def set_option(self, key: int, value: float):
+        """Tuning knobs (OPT_*); none of them changes the image."""
+        _check(lib().rtw_ctx_set_option(self._h, int(key), float(value)), "rtw_ctx_set_option")
+
     def render(self, cam: RtwCamera, params: RtwParams, out=None):
         """Render into `out`: None -> new numpy array; numpy array -> host buffer; int -> raw device pointer
         (e.g. torch_tensor.data_ptr()) of [rows][width][3] f32.  Returns (out, RtwStats)."""
@@ -539,6 +556,57 @@ class Renderer:
             ptr = C.c_void_p(int(out))
         _check(lib().rtw_ctx_render(self._h, C.byref(cam), C.byref(params), ptr, C.byref(st)), "rtw_ctx_render")
         return out, st
+
+
+class MultiRenderer:
+    """`rtw_mgpu`: one frame over several GPUs of a node from ONE process -- the fork / ordered join of the reference's row
+    tasks (Rust/src/viewport.rs:236-244).  `devices` are HIP ordinals and may repeat."""
+
+    def __init__(self, devices: Sequence[int]):
+        self._h = C.c_void_p()
+        self.n = len(devices)
+        arr = (C.c_int * max(1, self.n))(*[int(d) for d in devices])
+        _check(lib().rtw_mgpu_create(arr, self.n, C.byref(self._h)), "rtw_mgpu_create")
+        self._scene = None
+
+    def close(self):
+        if self._h:
+            lib().rtw_mgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, scene: Scene, t_begin: float = 0.0, t_end: float = 0.0):
+        self._scene = scene
+        _check(lib().rtw_mgpu_set_scene(self._h, C.byref(scene.pod), float(t_begin), float(t_end)), "rtw_mgpu_set_scene")
+
+    def set_option(self, key: int, value: float):
+        _check(lib().rtw_mgpu_set_option(self._h, int(key), float(value)), "rtw_mgpu_set_option")
+
+    def render(self, cam: RtwCamera, params: RtwParams, out=None):
+        """Full frame into `out` (None -> new numpy array; numpy array; int -> raw device pointer).
+        Returns (out, total RtwStats, [per-device RtwStats])."""
+        if out is None:
+            out = np.empty((params.height, params.width, 3), np.float32)
+        if isinstance(out, np.ndarray):
+            assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.size == params.height * params.width * 3
+            ptr = C.c_void_p(out.ctypes.data)
+        else:
+            ptr = C.c_void_p(int(out))
+        per = (RtwStats * max(1, self.n))()
+        tot = RtwStats()
+        _check(lib().rtw_mgpu_render(self._h, C.byref(cam), C.byref(params), ptr, per, C.byref(tot)), "rtw_mgpu_render")
+        return out, tot, list(per)[: self.n]
 
 
 def default_view(which: int):
@@ -580,6 +648,13 @@ def write_ppm(filename: str, img: np.ndarray):
     """write_ppm (C++/src/ppm_writer.cpp:3-27): P3 text."""
     a = np.ascontiguousarray(img, np.float32)
     _check(lib().rtw_write_ppm_f32(filename.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0]), "rtw_write_ppm_f32")
+
+
+def vec3_rotated(v, rot) -> np.ndarray:
+    """Vec3::rotated (Rust/src/vec3.rs:161-181)."""
+    out = (C.c_float * 3)()
+    lib().rtw_vec3_rotated(_fptr(_f3(v)), _fptr(_f3(rot)), out)
+    return np.array(list(out), np.float32)
 
 
 def device_count() -> int:

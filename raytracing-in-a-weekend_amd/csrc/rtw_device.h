@@ -130,23 +130,25 @@ __device__ __forceinline__ float rng_f32(Rng &r) { return rng_n24(r) * (1.0f / 1
 // `random::<f32>() * (max - min) + min` (vec3.rs:221-227) and to `i as f32 + random::<f32>()` (viewport.rs:290).
 __device__ __forceinline__ float rng_sym(Rng &r) { return __builtin_fmaf(rng_n24(r), 1.0f / 8388608.0f, -1.0f); }
 __device__ __forceinline__ float rng_offset(Rng &r, float c) { return __builtin_fmaf(rng_n24(r), 1.0f / 16777216.0f, c); }
-// vec3.rs:228-239
-__device__ __forceinline__ v3 random_unit_vec(Rng &r) {
+// vec3.rs:228-239.  `strict` (RTW_FLAG_CPP_DIFFUSE): the C++ twin accepts |p|^2 < 1 (C++/src/vec3.cpp:28-34), Rust <= 1.
+__device__ __forceinline__ v3 random_unit_vec(Rng &r, bool strict = false) {
     v3 p;
     for (;;) {
         p.x = rng_sym(r);                  // xi * (max - min) + min
         p.y = rng_sym(r);
         p.z = rng_sym(r);
-        if (p.x * p.x + p.y * p.y + p.z * p.z <= 1.0f) break;
+        const float l2 = p.x * p.x + p.y * p.y + p.z * p.z;
+        if (strict ? l2 < 1.0f : l2 <= 1.0f) break;
     }
     return unit(p);
 }
-// vec3.rs:240-254
-__device__ __forceinline__ void random_in_unit_disk(Rng &r, float &px, float &py) {
+// vec3.rs:240-254 (C++/headers/vec3.h:35-41 with `strict`)
+__device__ __forceinline__ void random_in_unit_disk(Rng &r, float &px, float &py, bool strict = false) {
     for (;;) {
         px = rng_sym(r);                   // xi * 2.0 - 1.0
         py = rng_sym(r);
-        if (px * px + py * py <= 1.0f) break;
+        const float l2 = px * px + py * py;
+        if (strict ? l2 < 1.0f : l2 <= 1.0f) break;
     }
 }
 
@@ -271,7 +273,8 @@ __device__ __forceinline__ MatP mat_params(const DevMat &d) {                   
     return m;
 }
 // `ud` is unit(dir), computed by the caller (the sky of a missing lane needs the same expression: one copy for the wave).
-__device__ __forceinline__ v3 on_hit(const MatP m, v3 normal, v3 dir, v3 ud, Rng &rng, float &cos_theta) {
+// `flags`: RTW_FLAG_CPP_* select the C++ twin's dialect (generic build only; a compile-time 0 elsewhere).
+__device__ __forceinline__ v3 on_hit(const MatP m, v3 point, v3 normal, v3 dir, v3 ud, Rng &rng, float &cos_theta, uint32_t flags) {
     const bool front = !(dot(dir, normal) > 0.0f);
     // Shared by both branches: unit(dir), and its mirror direction.  reflect(ud, -n) == reflect(ud, n)
     // bit for bit ((-n*2) * dot(ud,-n) == (n*2) * dot(ud,n): negation is exact and commutes with the
@@ -287,9 +290,21 @@ __device__ __forceinline__ v3 on_hit(const MatP m, v3 normal, v3 dir, v3 ud, Rng
         const bool cannot_refract = ratio * st > 1.0f;
         const float rfl = reflectance(ct, front ? m.r0_front : m.r0_back);
         bool do_reflect = cannot_refract;
-        if (!do_reflect) do_reflect = rfl > rng_f32(rng);   // xi drawn only when refraction is possible
+        // xi drawn only when refraction is possible; never by the C++ twin (Schlick term commented out, C++/headers/materials.h:106)
+        if (!do_reflect && !(flags & RTW_FLAG_CPP_DIELECTRIC)) do_reflect = rfl > rng_f32(rng);
         next = do_reflect ? refl : refract(ud, n, ratio);
         cos_theta = 0.0f;
+    } else if (flags & RTW_FLAG_CPP_DIFFUSE) {
+        // C++/headers/materials.h:113-117: sc = uniform_scatter(h, r).direction * (1 - m); reflect = metallic(h, r);
+        // direction = reflect.direction * m + sc -- with uniform_scatter = unit((point + normal + rand_unit) - point) and
+        // metallic = unit(reflect(unit(d), n)) (C++/src/materials.cpp:4-13), then near_zero -> normal (C++/src/sphere.cpp:29-31)
+        const v3 target = (point + normal) + random_unit_vec(rng, true);
+        const v3 sdir = unit(target - point);
+        const v3 mdir = unit(refl);
+        next = mdir * m.metallicness + sdir * (1.0f - m.metallicness);
+        cos_theta = (m.metallicness != 1.0f) ? dot(sdir, normal) : 0.0f;
+        if (__builtin_fabsf(next.x) < 1e-8f && __builtin_fabsf(next.y) < 1e-8f && __builtin_fabsf(next.z) < 1e-8f) next = normal;
+        return next;
     } else {
         const v3 target = normal + random_unit_vec(rng);      // drawn even for mirrors (materials.rs:142)
         const v3 sc = close_to_zero(target) ? normal : target;
@@ -303,7 +318,7 @@ __device__ __forceinline__ v3 on_hit(const MatP m, v3 normal, v3 dir, v3 ud, Rng
 // Rust2's Material trait objects (Rust2/src/objects/material.rs): MirrorGlass :130-162 (the Rust
 // dielectric's arithmetic), Mirror :75-83 (reflects the un-normalised direction), Lambertian :25-36
 // (unit(n + random_unit_vec())).  No degenerate-direction fix-up in Rust2's ray_color.
-__device__ __forceinline__ v3 on_hit_rust2(const MatP m, v3 normal, v3 dir, Rng &rng) {
+__device__ __forceinline__ v3 on_hit_rust2(const MatP m, v3 normal, v3 dir, Rng &rng, uint32_t flags) {
     if (m.opacity > 0.0f) {
         const bool front = !(dot(dir, normal) > 0.0f);
         const v3 n = front ? normal : -normal;
@@ -315,7 +330,7 @@ __device__ __forceinline__ v3 on_hit_rust2(const MatP m, v3 normal, v3 dir, Rng 
         const bool cannot_refract = ratio * st > 1.0f;
         const float rfl = reflectance(ct, front ? m.r0_front : m.r0_back);
         bool do_reflect = cannot_refract;
-        if (!do_reflect) do_reflect = rfl > rng_f32(rng);
+        if (!do_reflect && !(flags & RTW_FLAG_CPP_DIELECTRIC)) do_reflect = rfl > rng_f32(rng);
         return do_reflect ? reflect(ud, n) : refract(ud, n, ratio);
     }
     if (m.metallicness == 1.0f) return reflect(dir, normal);

@@ -91,6 +91,17 @@ using namespace rtw;
 
 extern "C" {
 
+// Vec3::rotated (vec3.rs:161-181): the host twin of rtw_device.h rotated() -- same sin / cos (std::sin(float), as rtw_ctx_set_scene
+// evaluates them for the device), same products in the same order (this TU is built with -ffp-contract=off).
+void rtw_vec3_rotated(const float v[3], const float rot[3], float out[3]) {
+    if (!v || !rot || !out) return;
+    const float as = std::sin(rot[0]), ac = std::cos(rot[0]), bs = std::sin(rot[1]), bc = std::cos(rot[1]), cs = std::sin(rot[2]), cc = std::cos(rot[2]);
+    const float x = v[0], y = v[1], z = v[2];
+    out[0] = x * bc * cc + y * (as * bs * cc - as * cc) + z * (ac * bs * cc + as * cs);
+    out[1] = x * bc * cs + y * (as * bs * cs + ac * cc) + z * (ac * bs * cs - as * cc);
+    out[2] = x * -bs + y * as * bc + z * ac * bc;
+}
+
 uint32_t rtw_part_rows(uint32_t height, uint32_t row_block, uint32_t part_index, uint32_t part_count) {
     if (part_count <= 1) return height;
     if (row_block == 0 || part_index >= part_count) return 0;
@@ -485,6 +496,7 @@ inline float box_area(const Box &b) {
 }
 
 struct Prim { Box box; float cen[3]; uint32_t sphere; };
+inline uint32_t ceil_log2(uint32_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }
 
 struct Builder {
     std::vector<Prim> prims;
@@ -506,7 +518,12 @@ struct Builder {
         uint32_t mid = first + count / 2;
         int best_axis = -1; float best_cost = FLT_MAX; float best_split = 0.0f;
         const int NB = 16;
-        if (depth + 4 < RTW_BVH_STACK) {
+        // Depth bound by construction (rtw_host.h: depth <= RTW_BVH_STACK): a median split of `count` spheres needs
+        // ceil(log2(count)) more levels, so the invariant is  depth + ceil(log2(count)) <= RTW_BVH_STACK.  It holds at the root
+        // (count <= 2^24) and a median split keeps it; a SAH split may leave count - 1 spheres on one side, so SAH is only tried
+        // when even that child keeps the invariant.  (Geometrically spaced spheres used to reach depth 27 under the old
+        // "SAH until depth 20" rule and overflowed the device stack.)
+        if (depth + 1 + ceil_log2(count - 1) <= RTW_BVH_STACK) {
             for (int ax = 0; ax < 3; ax++) {
                 float ext = cb.hi[ax] - cb.lo[ax];
                 if (!(ext > 0.0f)) continue;

@@ -41,6 +41,11 @@ struct JParser {
     bool ok = true;
     void ws() { while (p < end && std::isspace((unsigned char)*p)) p++; }
     bool eat(char c) { ws(); if (p < end && *p == c) { p++; return true; } return false; }
+    bool lit(const char *w) {                      // a literal, only when all of it lies inside [p, end)
+        const size_t n = std::strlen(w);
+        if ((size_t)(end - p) < n || std::memcmp(p, w, n) != 0) return false;
+        p += n; return true;
+    }
     std::string string() {
         std::string s;
         if (!eat('"')) { ok = false; return s; }
@@ -72,14 +77,19 @@ struct JParser {
             if (!eat(']')) ok = false;
         } else if (*p == '"') {
             v.kind = JVal::Str; v.str = string();
-        } else if (!std::strncmp(p, "true", 4) && end - p >= 4) { v.kind = JVal::Bool; v.num = 1; p += 4; }
-        else if (!std::strncmp(p, "false", 5) && end - p >= 5) { v.kind = JVal::Bool; p += 5; }
-        else if (!std::strncmp(p, "null", 4) && end - p >= 4) { p += 4; }
+        } else if (lit("true")) { v.kind = JVal::Bool; v.num = 1; }
+        else if (lit("false")) { v.kind = JVal::Bool; }
+        else if (lit("null")) { }
         else {
+            // the number token is copied into a bounded, NUL-terminated buffer first: strtod on the caller's text would scan past
+            // `end` when the buffer is not NUL-terminated and ends in digits
+            char tok[64]; size_t n = 0;
+            while (p + n < end && n + 1 < sizeof tok && (std::isdigit((unsigned char)p[n]) || (p[n] && std::strchr("+-.eE", p[n])))) n++;
+            std::memcpy(tok, p, n); tok[n] = 0;
             char *e = nullptr;
-            v.num = std::strtod(p, &e);
-            if (e == p) { ok = false; return v; }
-            v.kind = JVal::Num; p = e;
+            v.num = n ? std::strtod(tok, &e) : 0.0;
+            if (!n || e == tok) { ok = false; return v; }
+            v.kind = JVal::Num; p += e - tok;
         }
         return v;
     }
@@ -187,8 +197,10 @@ int rtw_scene_from_json(const char *text, size_t len,
             float row = 0, col = 0;
             const JVal *img = t->get("img");
             if (!read_f32(t->get("row"), row) || !read_f32(t->get("col"), col) || !img || img->kind != JVal::Arr) return RTW_E_INVALID;
+            // (validated as finite values in [1, 2^31) BEFORE the casts: a negative, NaN or huge f32 -> u32 is undefined behaviour)
+            if (!(row >= 1.0f && row < 2147483648.0f) || !(col >= 1.0f && col < 2147483648.0f)) return RTW_E_INVALID;
             const uint32_t w = (uint32_t)row, h = (uint32_t)col;
-            if (w == 0 || h == 0 || img->arr.size() < (size_t)w * h) return RTW_E_INVALID;
+            if (img->arr.size() < (size_t)w * h) return RTW_E_INVALID;
             if (w == 1 && h == 1) { if (!read_vec3(&img->arr[0], s.tex_color)) return RTW_E_INVALID; }
             else {
                 RtwTexture d; d.row = w; d.col = h; d.texel_offset = (uint32_t)(tl.size() / 3); d.reserved = 0;

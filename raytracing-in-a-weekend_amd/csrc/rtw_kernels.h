@@ -4,6 +4,9 @@
 #include "rtw_host.h"
 
 #define RTW_BLOCK 256   // 4 waves per workgroup
+#ifndef RTW_LIST_WALK_MAX_DEFAULT
+#define RTW_LIST_WALK_MAX_DEFAULT 8u   // RTW_OPT_LIST_WALK_MAX: scenes this small walk the list even when the BVH is asked for
+#endif
 
 namespace rtw {
 
@@ -34,7 +37,9 @@ struct KArgs {
     uint32_t k_base, k_end;       // compact rows [k_base, k_end) of this partition rendered by this launch (a band)
     uint32_t n_tiles;             // tiles_x * ceil((k_end - k_base) / 8)
     uint32_t chunk_len, n_chunks; // samples per work unit, units per pixel
-    float *samples;               // per-sample radiance, [n_tiles * n_chunks][chunk_len][64][3]
+    uint32_t bank_len;            // bank slots per unit and pixel: chunk_len (one per sample), or 1 with RTW_FLAG_CHUNK_SUMS
+    uint32_t flags;               // RtwParams.flags (RTW_FLAG_CPP_*: generic build only)
+    float *samples;               // per-sample radiance, [n_tiles * n_chunks][bank_len][64][3]
     uint32_t row_block, part_index, part_count;
     uint32_t tiles_x;             // ceil(width / 8)
     uint32_t total_work;          // 64 * n_tiles * n_chunks
@@ -56,5 +61,7 @@ struct KArgs {
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream);
 // Resident workgroups per CU for the kernel variant (occupancy API), >= 1.
 uint32_t kernel_blocks_per_cu(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes);
+// The kernel variant launch_render would pick, as an opaque id (key of the per-context occupancy cache).
+const void *kernel_id(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes);
 
 } // namespace rtw

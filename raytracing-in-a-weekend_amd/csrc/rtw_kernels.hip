@@ -115,7 +115,7 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
     px.rng_base = rng_pixel_base(A.seed_lo, A.seed_hi, px.j * A.width + px.i);
     px.s = rs.s0;
     px.s_end = rs.s1;
-    px.slot = (w >> 6) * 64u * A.chunk_len + (w & 63u);            // [unit][sample of chunk][pixel of tile]: lanes that finish the same
+    px.slot = (w >> 6) * 64u * A.bank_len + (w & 63u);            // [unit][sample of chunk][pixel of tile]: lanes that finish the same
                                                                    // sample of neighbouring pixels together fill whole sectors
     return px.s < px.s_end;
 }
@@ -141,7 +141,7 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
             random_in_unit_disk(pt.rng, rx, ry);
             o = cam_o + mk(rx, ry, 0.0f) * A.cam.lens_radius;
         } else {
-            random_in_unit_disk(pt.rng, rx, ry);             // always drawn (viewport.rs:288)
+            random_in_unit_disk(pt.rng, rx, ry, !SPEC && (A.flags & RTW_FLAG_CPP_DIFFUSE));   // always drawn (viewport.rs:288)
             o = cam_o + (ld3(A.cam.u) * rx + ld3(A.cam.v) * ry) * A.cam.lens_radius;
             if (samp<SPEC>(A) == RTW_SAMPLER_ROW) {              // viewport.rs:290-297
                 jx = rng_offset(pt.rng, (float)px.i);
@@ -181,7 +181,7 @@ __device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 ud, v
         return true;
     }
     if (integ<SPEC>(A) == RTW_INTEGRATOR_RUST2) {              // Rust2/src/viewport/ray_color.rs:17-31, front-to-back
-        const v3 nd2 = on_hit_rust2(mat, normal, pt.d, pt.rng);
+        const v3 nd2 = on_hit_rust2(mat, normal, pt.d, pt.rng, A.flags);
         pt.L = pt.L + emitted * pt.thr;
         pt.thr = pt.thr * cm;
         pt.o = point; pt.d = nd2;
@@ -190,7 +190,7 @@ __device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 ud, v
         return false;
     }
     float cos_theta;
-    const v3 nd = on_hit(mat, normal, pt.d, ud, pt.rng, cos_theta);
+    const v3 nd = on_hit(mat, point, normal, pt.d, ud, pt.rng, cos_theta, SPEC ? 0u : A.flags);
     if (integ<SPEC>(A) == RTW_INTEGRATOR_BG_COLOR) {           // ray_color.rs:64-88, front-to-back
         // lambertian_scatter_pdf (materials.rs:5-13); pdf == 0 makes the reference's `color * pdf / pdf` a 0/0
         const float pdf = cos_theta > 0.0f ? cos_theta * 0.318309886183790671538f : 0.0f;
@@ -760,7 +760,8 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
 // ================================================================================================
 typedef void (*kernel_fn)(const KArgs);
 static bool is_common_config(const KArgs &a) {
-    return a.integrator == RTW_INTEGRATOR_GRADIENT && a.sampler == RTW_SAMPLER_ROW && a.depth >= 1;
+    return a.integrator == RTW_INTEGRATOR_GRADIENT && a.sampler == RTW_SAMPLER_ROW && a.depth >= 1 &&
+           (a.flags & (RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE)) == 0u;
 }
 template <int SPEC>
 static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, bool lds_nodes) {
@@ -793,6 +794,10 @@ uint32_t kernel_blocks_per_cu(const KArgs &a, bool moving, uint32_t accel, bool 
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pick_kernel(a, moving, accel, lds_nodes), RTW_BLOCK, a.lds_bytes) != hipSuccess || n < 1) n = 1;
     return (uint32_t)(n > 8 ? 8 : n);
+}
+
+const void *kernel_id(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes) {
+    return (const void *)pick_kernel(a, moving, accel, lds_nodes);
 }
 
 } // namespace rtw

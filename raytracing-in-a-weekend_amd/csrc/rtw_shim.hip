@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
+#include <utility>
 #include <vector>
 
 using namespace rtw;
@@ -30,6 +32,8 @@ struct rtw_ctx {
     // scene
     bool has_scene = false;
     bool has_textures = false;
+    bool bvh_ok = true;                  // false: the tree is deeper than the device stack (never with build_bvh's invariant; checked anyway)
+    float t_begin = 0.0f, t_end = 0.0f;  // ray.time range the BVH bounds were expanded for (rtw_ctx_set_scene)
     DevScene sc{};
     float bg[3] = { 0, 0, 0 };
     void *d_geom = nullptr, *d_vel = nullptr, *d_mat = nullptr, *d_tex = nullptr, *d_texels = nullptr;
@@ -40,10 +44,32 @@ struct rtw_ctx {
     // scratch
     uint32_t *d_queue = nullptr;
     unsigned long long *d_stats = nullptr;
+    unsigned long long *h_stats = nullptr;   // pinned: the counter read-back is a true async copy
     float *d_out = nullptr;
     size_t d_out_cap = 0;
-    float *d_samples = nullptr;          // per-sample radiance bank (see rtw_ctx_render)
+    float *d_samples = nullptr;          // per-sample radiance bank (see render_enqueue)
     size_t d_samples_cap = 0;
+    // options (rtw_ctx_set_option)
+    uint32_t opt_chunk_len = 4;          // tuned on the bench frame: 4-6 is the flat optimum (1: 13.5, 2: 17.0, 4: 17.9, 8: 17.3, 16: 16.8 Gsegments/s)
+    uint64_t opt_bank_bytes = 48ull << 30;
+    int opt_lds_geom = -1;
+    uint32_t opt_blocks_per_cu = 0;
+    uint32_t opt_list_walk_max = RTW_LIST_WALK_MAX_DEFAULT;
+    // caches of per-call driver queries (each costs tens of microseconds: visible on small frames)
+    std::map<std::pair<const void *, uint32_t>, uint32_t> occupancy;    // (kernel, dynamic LDS bytes) -> resident workgroups per CU
+    const void *attr_ptr = nullptr; bool attr_on_device = false; int attr_device = -1;   // last out_rgb classified
+    // the render in flight between render_enqueue and render_wait
+    struct Pending {
+        bool active = false;
+        uint32_t n_rows = 0;
+        std::chrono::steady_clock::time_point t0;
+    } pend;
+};
+
+// Where a render's rows go.
+struct OutSpec {
+    float *base;        // compact [rows][width][3] buffer, or -- scatter -- the full [height][width][3] frame
+    bool scatter;       // copy every row block to its image rows of the full frame (multi-GPU: no gather buffer, no de-interleave pass)
 };
 
 // The device records of a sphere list (sphere.rs:13-20 + materials.rs:15-20)
@@ -140,6 +166,7 @@ int rtw_ctx_create(int device, rtw_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_stats, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stats, 16 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) { g_last_hip = (int)e; rtw_ctx_destroy(c); return RTW_E_HIP; }
     c->stream = c->own_stream;
     *out = c;
@@ -159,6 +186,7 @@ void rtw_ctx_destroy(rtw_ctx *c) {
     free_scene(c);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_samples) (void)hipFree(c->d_samples);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -254,6 +282,8 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     c->bvh.big_geom = (const f4 *)c->d_big_geom; c->bvh.big_vel = (const f4 *)c->d_big_vel;
     c->bvh.big_index = (const uint32_t *)c->d_big_index; c->bvh.n_big = (uint32_t)bb.big.size();
     c->bvh.root = bb.root; c->bvh.depth = bb.depth;
+    c->bvh_ok = bb.depth <= RTW_BVH_STACK;        // build_bvh guarantees it; a deeper tree would overflow the per-lane LDS stack
+    c->t_begin = std::fmin(t_begin, t_end); c->t_end = std::fmax(t_begin, t_end);
     c->bvh.cx = bb.centre[0]; c->bvh.cy = bb.centre[1]; c->bvh.cz = bb.centre[2];
     c->bvh.centre_radius = bb.centre_radius;
     c->bvh.r_max2 = bb.r_max * bb.r_max * 1.000001f;
@@ -270,14 +300,43 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     return RTW_OK;
 }
 
-int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *out_rgb, RtwStats *stats) {
-    if (!c || !cam || !p || !out_rgb) return RTW_E_INVALID;
+} // extern "C"
+
+// Copy the compact rows of partition (row_block, part_index, part_count) from `src` (device) to their image rows of the
+// full frame `dst` (host, or device memory of any GPU): the blocks a partition owns are equally spaced in the frame, so ONE
+// strided 2-D copy moves all the full blocks, and a second, 1-D, the ragged last block when this partition owns it.
+static int scatter_rows(rtw_ctx *c, const float *src, float *dst, uint32_t width, uint32_t height, uint32_t row_block,
+                        uint32_t part_index, uint32_t part_count) {
+    const size_t row_bytes = (size_t)width * 3 * sizeof(float);
+    if (part_count <= 1) { HIP_TRY(hipMemcpyAsync(dst, src, row_bytes * height, hipMemcpyDefault, c->stream)); return RTW_OK; }
+    const uint32_t n_blocks = (height + row_block - 1) / row_block;
+    uint32_t mine = 0, full = 0;                                    // blocks b = part_index + k * part_count < n_blocks
+    if (part_index < n_blocks) mine = (n_blocks - 1 - part_index) / part_count + 1;
+    const bool ragged = height % row_block != 0;
+    const bool own_last = mine > 0 && (part_index + (mine - 1) * part_count) == n_blocks - 1;
+    full = mine - ((ragged && own_last) ? 1u : 0u);
+    const size_t block_bytes = row_bytes * row_block;
+    if (full) HIP_TRY(hipMemcpy2DAsync((char *)dst + (size_t)part_index * block_bytes, (size_t)part_count * block_bytes, src, block_bytes,
+                                       block_bytes, full, hipMemcpyDefault, c->stream));
+    if (full < mine) {
+        const uint32_t b = part_index + full * part_count;
+        HIP_TRY(hipMemcpyAsync((char *)dst + (size_t)b * block_bytes, (const char *)src + (size_t)full * block_bytes,
+                               row_bytes * (height - b * row_block), hipMemcpyDefault, c->stream));
+    }
+    return RTW_OK;
+}
+
+// Launch one render on the context's stream; nothing here waits for the GPU (apart from a first-use hipMalloc).
+static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out) {
+    if (!c || !cam || !p || !out.base) return RTW_E_INVALID;
+    if (c->pend.active) return RTW_E_INVALID;
     if (!c->has_scene) return RTW_E_NO_SCENE;
     if (p->width == 0 || p->height == 0 || p->samples == 0) return RTW_E_INVALID;
     if (p->integrator > RTW_INTEGRATOR_RUST2 || p->sampler > RTW_SAMPLER_NO_RAND || p->accel > RTW_ACCEL_BVH) return RTW_E_INVALID;
     if (p->part_count > 1 && (p->row_block == 0 || p->part_index >= p->part_count)) return RTW_E_INVALID;
     if ((uint64_t)p->width * p->height >= (1ull << 32)) return RTW_E_INVALID;
-    auto t0 = std::chrono::steady_clock::now();
+    if (p->flags & RTW_FLAG_CHUNK_SUMS) return RTW_E_UNSUPPORTED;    // TODO(round 2): declared in rtw.h, kernel support pending
+    c->pend.t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(c->device));
 
     // The BVH's pruning is proven against the reference's ROUNDED quadratic (DESIGN.md "Conservative traversal"), which presumes
@@ -297,12 +356,21 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
         const double nn = norm(N);
         const double lo = nn > 0.0 ? std::fabs(P[0] * N[0] + P[1] * N[1] + P[2] * N[2]) / nn : 0.0;
         if (!(hi <= 1e15) || !(lo >= 1e-15)) accel = RTW_ACCEL_BRUTE;
+        // The tree's bounds cover ray.time in [t_begin, t_end] only (rtw_ctx_set_scene): outside it a moving sphere can leave its box
+        if (c->sc.moving) {
+            const float ta = cam->time0, tb = cam->time0 + cam->shutter;
+            if (!(std::fmin(ta, tb) >= c->t_begin && std::fmax(ta, tb) <= c->t_end)) accel = RTW_ACCEL_BRUTE;
+        }
+        if (!c->bvh_ok) accel = RTW_ACCEL_BRUTE;
+        // a handful of spheres: the list walk IS the fastest closest-hit (the traversal scheduler only costs)
+        if (c->sc.n <= c->opt_list_walk_max) accel = RTW_ACCEL_BRUTE;
     }
 
     KArgs a;
     std::memset(&a, 0, sizeof a);
     a.cam = *cam; a.sc = c->sc; a.bvh = c->bvh; a.geom = c->geom;
     if (p->flags & RTW_FLAG_GLOBAL_NODES) a.bvh.nodes16 = nullptr;
+    a.flags = p->flags;
     a.width = p->width; a.height = p->height;
     const uint32_t n_rows = rtw_part_rows(p->height, p->row_block, p->part_index, p->part_count);
     a.row_block = p->row_block ? p->row_block : 1; a.part_index = p->part_index; a.part_count = p->part_count;
@@ -321,17 +389,19 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     // so that no lane owns more than chunk_len sequential paths (the slowest PIXEL used to set a ~50 ms tail).
     // Every sample's radiance is banked in HBM and added in order by resolve_kernel: 12 B per camera ray
     // (12.4 GB for 1920x1080x500) -- the image is rendered in bands of tile rows when that exceeds the budget.
-    uint32_t chunk_len = 4;          // tuned on the bench frame: 4-6 is the flat optimum (1: 13.5, 2: 17.0, 4: 17.9, 8: 17.3, 16: 16.8 Gsegments/s)
-    if (const char *e = getenv("RTW_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 4096) chunk_len = (uint32_t)v; }
+    // RTW_FLAG_CHUNK_SUMS banks one partial sum per unit instead (bank_len = 1 slot per unit and pixel).
+    uint32_t chunk_len = c->opt_chunk_len;
     if (chunk_len > a.n_samples) chunk_len = a.n_samples;
     a.chunk_len = chunk_len;
     a.n_chunks = (a.n_samples + chunk_len - 1) / chunk_len;
-    const uint64_t slots_per_tile_row = (uint64_t)a.tiles_x * a.n_chunks * 64ull * chunk_len;
-    uint64_t budget = 48ull << 30;
-    if (const char *e = getenv("RTW_SAMPLE_BUF_GB")) { double v = atof(e); if (v > 0.0) budget = (uint64_t)(v * (double)(1ull << 30)); }
-    uint64_t max_slots = budget / 12; if (max_slots > 0xFFFFFFF0ull) max_slots = 0xFFFFFFF0ull;
+    a.bank_len = (p->flags & RTW_FLAG_CHUNK_SUMS) ? 1u : chunk_len;
+    const uint64_t slots_per_tile_row = (uint64_t)a.tiles_x * a.n_chunks * 64ull * a.bank_len;
+    uint64_t max_slots = c->opt_bank_bytes / 12; if (max_slots > 0xFFFFFFF0ull) max_slots = 0xFFFFFFF0ull;
+    // (work items are counted in 32 bits as well: 64 per tile and chunk)
+    const uint64_t items_per_tile_row = (uint64_t)a.tiles_x * a.n_chunks * 64ull;
     const uint32_t tile_rows = (n_rows + 7) / 8;
     uint64_t band_tile_rows = max_slots / (slots_per_tile_row ? slots_per_tile_row : 1);
+    if (band_tile_rows > 0xFFFFFFF0ull / items_per_tile_row) band_tile_rows = 0xFFFFFFF0ull / items_per_tile_row;
     if (band_tile_rows == 0) return RTW_E_NOMEM;                  // one row of tiles does not fit the budget
     if (band_tile_rows > tile_rows) band_tile_rows = tile_rows;
     const size_t sample_bytes = (size_t)(band_tile_rows * slots_per_tile_row) * 12;
@@ -343,13 +413,19 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     }
     a.samples = c->d_samples;
 
+    // destination: the kernels write compact rows either straight into the caller's device buffer or into the context's
     const size_t out_bytes = (size_t)n_rows * p->width * 3 * sizeof(float);
-    hipPointerAttribute_t attr;
-    bool out_on_device = false;
-    if (hipPointerGetAttributes(&attr, out_rgb) == hipSuccess) {
-        out_on_device = attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
-    } else (void)hipGetLastError();
-    if (out_on_device) a.out = out_rgb;
+    if (c->attr_ptr != out.base) {
+        hipPointerAttribute_t attr;
+        c->attr_on_device = false; c->attr_device = -1;
+        if (hipPointerGetAttributes(&attr, out.base) == hipSuccess) {
+            c->attr_on_device = attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+            c->attr_device = attr.device;
+        } else (void)hipGetLastError();
+        c->attr_ptr = out.base;
+    }
+    const bool direct = c->attr_on_device && c->attr_device == c->device && !(out.scatter && p->part_count > 1);
+    if (direct) a.out = out.base;
     else {
         if (c->d_out_cap < out_bytes) {
             if (c->d_out) (void)hipFree(c->d_out);
@@ -364,7 +440,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
     if (accel == RTW_ACCEL_BVH) {
         const bool ldsn = a.bvh.nodes16 != nullptr;
         // sentinel + one entry per tree level + the slot above the top the descend step always writes
-        uint32_t levels = c->bvh.depth + 3; if (levels < 4) levels = 4; if (levels > RTW_BVH_STACK + 3) levels = RTW_BVH_STACK + 3;
+        uint32_t levels = c->bvh.depth + 3; if (levels < 4) levels = 4;
         uint32_t off = levels * RTW_BLOCK * (ldsn ? 2u : 4u);
         off = (off + 15u) & ~15u;
         if (ldsn) {
@@ -372,15 +448,21 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
             // sphere geometry rides along only while the workgroup stays under 1/6 of the CU's 160 KiB, i.e. while
             // it does not cost a resident workgroup at the kernel's register budget (6 waves/SIMD)
             bool geom = off + c->sc.n * 16u <= 160u * 1024u / 6u;
-            if (const char *e = getenv("RTW_LDS_GEOM")) geom = atoi(e) != 0 && c->sc.n <= RTW_LDS_GEOM_MAX;
+            if (c->opt_lds_geom >= 0) geom = c->opt_lds_geom != 0 && c->sc.n <= RTW_LDS_GEOM_MAX;
             if (geom) { a.lds_geom_off = off; off += c->sc.n * 16u; }
         }
         a.lds_bytes = off;
     }
 
     // persistent grid: as many workgroups as the kernel's registers let be resident, capped by the work
-    uint32_t per_cu = kernel_blocks_per_cu(a, c->sc.moving != 0, accel, c->bvh.nodes16 != nullptr && !(p->flags & RTW_FLAG_GLOBAL_NODES));
-    if (const char *e = getenv("RTW_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = (uint32_t)v; }   // occupancy experiments
+    uint32_t per_cu = c->opt_blocks_per_cu;
+    if (per_cu == 0) {
+        const bool ldsn = c->bvh.nodes16 != nullptr && !(p->flags & RTW_FLAG_GLOBAL_NODES);
+        const auto key = std::make_pair(kernel_id(a, c->sc.moving != 0, accel, ldsn), a.lds_bytes);
+        auto it = c->occupancy.find(key);
+        if (it == c->occupancy.end()) it = c->occupancy.emplace(key, kernel_blocks_per_cu(a, c->sc.moving != 0, accel, ldsn)).first;
+        per_cu = it->second;
+    }
 
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -388,7 +470,7 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
         const uint32_t tr1 = tr0 + (uint32_t)band_tile_rows < tile_rows ? tr0 + (uint32_t)band_tile_rows : tile_rows;
         a.k_base = tr0 * 8; a.k_end = tr1 * 8 < n_rows ? tr1 * 8 : n_rows;
         a.n_tiles = a.tiles_x * (tr1 - tr0);
-        a.total_work = a.n_tiles * a.n_chunks * 64u;              // < 2^32 by the slot bound above
+        a.total_work = a.n_tiles * a.n_chunks * 64u;              // < 2^32 by the item bound above
         uint32_t grid = (uint32_t)c->n_cu * per_cu;
         const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
         if (grid > need) grid = need ? need : 1;
@@ -398,28 +480,154 @@ int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *
         if (tile_rows == 0) break;
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    unsigned long long h_stats[16];
-    HIP_TRY(hipMemcpyAsync(h_stats, c->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, c->stream));
-    if (!out_on_device) HIP_TRY(hipMemcpyAsync(out_rgb, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (out.scatter) {
+        if (!direct) { int rc = scatter_rows(c, c->d_out, out.base, p->width, p->height, a.row_block, p->part_index, p->part_count); if (rc != RTW_OK) return rc; }
+    } else if (!direct) HIP_TRY(hipMemcpyAsync(out.base, c->d_out, out_bytes, hipMemcpyDefault, c->stream));
+    c->pend.active = true; c->pend.n_rows = n_rows;
+    return RTW_OK;
+}
+
+// Wait for the render launched by render_enqueue and report its counters.
+static int render_wait(rtw_ctx *c, RtwStats *stats) {
+    if (!c || !c->pend.active) return RTW_E_INVALID;
+    c->pend.active = false;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    const unsigned long long *h_stats = c->h_stats;
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->camera_rays = h_stats[0]; stats->segments = h_stats[1];
         stats->sphere_tests = h_stats[2]; stats->node_tests = h_stats[3];
-        stats->nan_pixels = (uint32_t)h_stats[4]; stats->rows = n_rows;
+        stats->nan_pixels = (uint32_t)h_stats[4]; stats->rows = c->pend.n_rows;
         stats->quad_tests = h_stats[14];
         stats->kernel_ms = ms;
         for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
+#if defined(RTW_STAMP) || defined(RTW_ENDTIMES)     // diagnostic builds only (scripts/gpu_endtimes.py)
         if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu\n", h_stats[11], h_stats[12], h_stats[13]);
         if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15]) {   // RTW_ENDTIMES build: [12] longest wave lifetime [13] sum of wave lifetimes [15] waves
             std::fprintf(stderr, "rtw endtimes: %llu waves, longest lifetime %llu ticks, mean lifetime %.1f %% of it\n", h_stats[15], h_stats[12],
                          100.0 * (double)h_stats[13] / (double)h_stats[15] / (double)h_stats[12]);
         }
-        stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+#endif
+        stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->pend.t0).count();
     }
     return RTW_OK;
+}
+
+struct rtw_mgpu {
+    std::vector<rtw_ctx *> ctx;
+};
+
+extern "C" {
+
+int rtw_ctx_set_option(rtw_ctx *c, uint32_t key, double v) {
+    if (!c || !(v == v)) return RTW_E_INVALID;
+    switch (key) {
+    case RTW_OPT_CHUNK_LEN:      if (!(v >= 1.0 && v <= 4096.0)) return RTW_E_INVALID; c->opt_chunk_len = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_SAMPLE_BANK_GB: if (!(v > 0.0 && v <= 1048576.0)) return RTW_E_INVALID; c->opt_bank_bytes = (uint64_t)(v * (double)(1ull << 30)); return RTW_OK;
+    case RTW_OPT_LDS_GEOM:       if (!(v >= -1.0 && v <= 1.0)) return RTW_E_INVALID; c->opt_lds_geom = (int)v; return RTW_OK;
+    case RTW_OPT_BLOCKS_PER_CU:  if (!(v >= 0.0 && v <= 8.0)) return RTW_E_INVALID; c->opt_blocks_per_cu = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_LIST_WALK_MAX:  if (!(v >= 0.0 && v <= 4294967295.0)) return RTW_E_INVALID; c->opt_list_walk_max = (uint32_t)v; return RTW_OK;
+    default: return RTW_E_INVALID;
+    }
+}
+
+int rtw_ctx_render(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float *out_rgb, RtwStats *stats) {
+    int rc = render_enqueue(c, cam, p, OutSpec{ out_rgb, false });
+    if (rc != RTW_OK) return rc;
+    return render_wait(c, stats);
+}
+
+// ---- one frame over several GPUs (rtw.h) -------------------------------------------------------------
+int rtw_mgpu_create(const int *devices, uint32_t n, rtw_mgpu **out) {
+    if (!out) return RTW_E_INVALID;
+    *out = nullptr;
+    if (!devices || n == 0 || n > 64) return RTW_E_INVALID;
+    if (rtw_device_count() <= 0) return RTW_E_NO_DEVICE;
+    rtw_mgpu *m = new (std::nothrow) rtw_mgpu();
+    if (!m) return RTW_E_NOMEM;
+    for (uint32_t k = 0; k < n; k++) {
+        rtw_ctx *c = nullptr;
+        int rc = rtw_ctx_create(devices[k], &c);
+        if (rc != RTW_OK) { rtw_mgpu_destroy(m); return rc; }
+        m->ctx.push_back(c);
+    }
+    // let every device write into the others' memory (frames that live in one GPU's HBM); failure is fine: the copies then go
+    // through the host, which hipMemcpyDefault does by itself
+    for (uint32_t k = 0; k < n; k++) for (uint32_t j = 0; j < n; j++) {
+        if (devices[k] == devices[j]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[k], devices[j]) == hipSuccess && can) {
+            (void)hipSetDevice(devices[k]);
+            if (hipDeviceEnablePeerAccess(devices[j], 0) != hipSuccess) (void)hipGetLastError();   // (already enabled is an error code too)
+        } else (void)hipGetLastError();
+    }
+    *out = m;
+    return RTW_OK;
+}
+
+void rtw_mgpu_destroy(rtw_mgpu *m) {
+    if (!m) return;
+    for (rtw_ctx *c : m->ctx) rtw_ctx_destroy(c);
+    delete m;
+}
+
+int rtw_mgpu_set_scene(rtw_mgpu *m, const RtwScene *scene, float t_begin, float t_end) {
+    if (!m) return RTW_E_INVALID;
+    for (rtw_ctx *c : m->ctx) { int rc = rtw_ctx_set_scene(c, scene, t_begin, t_end); if (rc != RTW_OK) return rc; }
+    return RTW_OK;
+}
+
+int rtw_mgpu_set_option(rtw_mgpu *m, uint32_t key, double value) {
+    if (!m) return RTW_E_INVALID;
+    for (rtw_ctx *c : m->ctx) { int rc = rtw_ctx_set_option(c, key, value); if (rc != RTW_OK) return rc; }
+    return RTW_OK;
+}
+
+int rtw_mgpu_render(rtw_mgpu *m, const RtwCamera *cam, const RtwParams *params, float *out_rgb, RtwStats *per_device, RtwStats *total) {
+    if (!m || !cam || !params || !out_rgb || params->part_count > 1) return RTW_E_INVALID;
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n = (uint32_t)m->ctx.size();
+    // fork: viewport.rs:236-240 spawns one task per row; here one asynchronous launch sequence per device
+    int rc = RTW_OK;
+    uint32_t launched = 0;
+    for (; launched < n; launched++) {
+        RtwParams q = *params;
+        q.row_block = params->row_block ? params->row_block : 8u;
+        q.part_index = launched; q.part_count = n;
+        rc = render_enqueue(m->ctx[launched], cam, &q, OutSpec{ out_rgb, true });
+        if (rc != RTW_OK) break;
+    }
+    // join: viewport.rs:241-244 awaits the tasks in order
+    RtwStats sum; std::memset(&sum, 0, sizeof sum);
+    for (uint32_t k = 0; k < launched; k++) {
+        RtwStats st;
+        const int rw = render_wait(m->ctx[k], &st);
+        if (rw != RTW_OK) { if (rc == RTW_OK) rc = rw; continue; }
+        if (per_device) per_device[k] = st;
+        sum.camera_rays += st.camera_rays; sum.segments += st.segments; sum.sphere_tests += st.sphere_tests;
+        sum.node_tests += st.node_tests; sum.quad_tests += st.quad_tests; sum.nan_pixels += st.nan_pixels; sum.rows += st.rows;
+        for (int i = 0; i < 3; i++) { sum.phase_steps[i] += st.phase_steps[i]; sum.phase_lanes[i] += st.phase_lanes[i]; }
+        if (st.kernel_ms > sum.kernel_ms) sum.kernel_ms = st.kernel_ms;
+    }
+    sum.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (total) *total = sum;
+    return rc;
+}
+
+int rtw_render_multi_gpu(const int *devices, uint32_t n_devices, const RtwCamera *cam, const RtwScene *scene,
+                         const RtwParams *params, float *out_rgb, RtwStats *per_device) {
+    if (!cam || !scene || !params) return RTW_E_INVALID;
+    rtw_mgpu *m = nullptr;
+    int rc = rtw_mgpu_create(devices, n_devices, &m);
+    if (rc != RTW_OK) return rc;
+    rc = rtw_mgpu_set_scene(m, scene, cam->time0, cam->time0 + cam->shutter);
+    if (rc == RTW_OK) rc = rtw_mgpu_render(m, cam, params, out_rgb, per_device, nullptr);
+    rtw_mgpu_destroy(m);
+    return rc;
 }
 
 int rtw_ctx_render_multi(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, float fps, uint32_t start_frame, uint32_t n_frames,

@@ -46,8 +46,16 @@ def lib():
         L.rtw_oracle_rng_seed.restype = None
         L.rtw_oracle_rng_next.argtypes = [C.POINTER(C.c_uint32)]
         L.rtw_oracle_rng_next.restype = C.c_float
+        L.rtw_oracle_rotated.argtypes = [fp, fp, fp]
+        L.rtw_oracle_rotated.restype = None
         _lib = L
     return _lib
+
+
+def rotated(v, rot):
+    out = (C.c_float * 3)()
+    lib().rtw_oracle_rotated((C.c_float * 3)(*v), (C.c_float * 3)(*rot), out)
+    return np.array(list(out), np.float32)
 
 
 def have_ref():

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 17, names
     for n in names:
         assert hasattr(L, n), f"librtw_hip.so does not export {n}"
-    assert L.rtw_abi_version() == 2
+    assert L.rtw_abi_version() == 3
 
 
 def test_oracle_exports_every_declared_symbol():
@@ -316,3 +316,79 @@ def test_quantiser_against_the_reference_writer_test_image():
     img[:, :, 1] = i[:, None]
     img[:, :, 2] = np.float32(0.25)
     assert np.array_equal(R.quantize_u8(img), gold)
+
+
+# ---- round 2: multi-GPU entry points, builder depth bound, bounded JSON reads, the reference's rotation KATs ----------
+def test_multi_gpu_entry_points_without_a_device():
+    """rtw_mgpu_* / rtw_render_multi_gpu (the fork / ordered join of viewport.rs:236-244 over GPUs) fail loudly without
+    a GPU: RTW_E_NO_DEVICE, never a CPU render."""
+    if R.device_count() > 0:
+        pytest.skip("a GPU is present")
+    L = R.lib()
+    h = C.c_void_p()
+    dev = (C.c_int * 3)(0, 0, 0)
+    assert L.rtw_mgpu_create(dev, 3, C.byref(h)) == -2 and not h.value
+    assert L.rtw_mgpu_create(None, 3, C.byref(h)) == -1 and L.rtw_mgpu_create(dev, 0, C.byref(h)) == -1
+    scene = R.Scene.generate(R.SCENE_C1)
+    cam, p = R.default_view(R.SCENE_C1)
+    out = np.zeros((p.height, p.width, 3), np.float32)
+    assert L.rtw_render_multi_gpu(dev, 3, C.byref(cam), C.byref(scene.pod), C.byref(p), out.ctypes.data_as(C.c_void_p), None) == -2
+    assert not out.any()
+    with pytest.raises(R.RtwError):
+        R.MultiRenderer([0, 0])
+    L.rtw_mgpu_destroy(None)            # like free(NULL)
+    assert L.rtw_mgpu_render(None, C.byref(cam), C.byref(p), out.ctypes.data_as(C.c_void_p), None, None) == -1
+
+
+def geometric_scene(n=400, ratio=1.2):
+    """Equal spheres at x = ratio^i: every SAH split peels a few spheres off the dense end (depth 27)."""
+    return R.Scene([R.Sphere.with_albedo((float(np.float32(ratio) ** i), 0.0, -5.0), 0.01, (0.5, 0.5, 0.5)) for i in range(n)])
+
+
+@pytest.mark.parametrize("n,ratio", [(400, 1.2), (3000, 1.01), (64, 4.0), (1000, 1.05)])
+def test_bvh_depth_is_bounded_by_construction(n, ratio):
+    """The builder's invariant depth + ceil(log2(count)) <= RTW_BVH_STACK (24) holds on skewed scenes."""
+    sc = geometric_scene(n, ratio)
+    nn, depth, nbig, f16 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    assert R.lib().rtw_bvh_validate(C.byref(sc.pod), 0.0, 0.0, C.byref(nn), C.byref(depth), C.byref(nbig), C.byref(f16)) == 0
+    assert depth.value <= 24 and nn.value + nbig.value + 1 >= n
+
+
+def test_json_parser_never_reads_past_len():
+    """rtw_scene_from_json takes (text, len): literals and numbers at the very end of a buffer that is NOT
+    NUL-terminated must not be scanned past `len`."""
+    L = R.lib()
+    ns = C.c_uint32()
+    doc = b'{"spheres":[]}'
+    # the document followed by bytes that would extend a number / complete a literal if the parser ran on
+    for tail in (b"123456", b"ue", b"e+9", b"]}"):
+        buf = C.create_string_buffer(doc + tail, len(doc) + len(tail))       # no trailing NUL inside the window
+        assert L.rtw_scene_from_json(buf, len(doc), None, 0, C.byref(ns), None, 0, None, None, 0, None) == 0 and ns.value == 0
+    for frag in (b"tr", b"12", b"-", b'{"spheres":[1.5', b'{"spheres":[tru', b"nul"):
+        buf = C.create_string_buffer(frag + b"e9999}]}", len(frag) + 8)
+        assert L.rtw_scene_from_json(buf, len(frag), None, 0, C.byref(ns), None, 0, None, None, 0, None) == -1
+    # texture dimensions are validated before they are converted to integers
+    sph = ('{"origin":{"x":0,"y":0,"z":0},"radius":1,"col_mod":{"x":1,"y":1,"z":1},"material":{"metallicness":0,"opacity":0,"ir":1},'
+           '"texture":{"row":%s,"col":%s,"img":[{"x":1,"y":1,"z":1}]}}')
+    for row, col in (("-1", "1"), ("1e30", "1"), ("1", "-5"), ("0", "1"), ("4294967296", "1")):
+        raw = ('{"spheres":[' + sph % (row, col) + "]}").encode()
+        assert L.rtw_scene_from_json(raw, len(raw), None, 0, C.byref(ns), None, 0, None, None, 0, None) == -1, (row, col)
+    raw = ('{"spheres":[' + sph % ("1", "1") + "]}").encode()
+    assert L.rtw_scene_from_json(raw, len(raw), None, 0, C.byref(ns), None, 0, None, None, 0, None) == 0 and ns.value == 1
+
+
+def test_rotated_known_answers_of_the_reference():
+    """The reference's own rotation_tests (Rust/src/vec3.rs:363-404; its Vec3 == is |d| < 1e-7 per component,
+    vec3.rs:17-21) on the host mirror and on the oracle, which must also agree with each other bit for bit."""
+    from tests import oracle_binding as O
+    PI = np.float32(np.pi)
+    rot1 = (float(PI / np.float32(6.0)), 0.0, 0.0)
+    rot2 = (0.0, 0.0, float(PI / np.float32(6.0)))
+    c, s = np.float32(np.cos(np.float32(rot2[2]))), np.float32(np.sin(np.float32(rot2[2])))
+    cases = [((1.0, 0.0, 0.0), rot1, (1.0, 0.0, -0.0)),                   # x: rot1.y.cos() * rot1.z.cos() == 1
+             ((1.0, 0.0, 0.0), rot2, (c, s, 0.0)),
+             ((1.0, 0.0, 1.0), rot2, (c, s, 1.0))]
+    for v, rot, want in cases:
+        a, b = R.vec3_rotated(v, rot), O.rotated(v, rot)
+        assert a.tobytes() == b.tobytes()
+        assert np.abs(a - np.float32(want)).max() < 1e-7, (v, rot, a, want)

@@ -347,27 +347,32 @@ def test_c4_c5_full_size(gpu, which):
         assert ulp_diff(a[rows], ref).max() <= 2
 
 
-def test_sample_bank_bands_and_chunk_lengths(gpu, monkeypatch):
+def test_sample_bank_bands_and_chunk_lengths(rtw):
     """The per-sample radiance bank may be rendered in bands of tile rows (memory budget) and with any chunk
     length (samples per work unit): neither changes a bit of the image."""
     scene, cam, p = small_view(R.SCENE_C2, 200, 120, 37)
     p.gamma, p.accel = 1.0, R.ACCEL_BVH
     ref, st_ref = O.render(cam, scene, p)
-    gpu.set_scene(scene)
-    base, st = gpu.render(cam, p)
-    assert np.array_equal(base, ref) and st.segments == st_ref.segments
-    for chunk in ("1", "5", "37", "64"):
-        monkeypatch.setenv("RTW_CHUNK", chunk)
+    with rtw.Renderer(0) as gpu:                             # own context: the options below must not leak into other tests
+        gpu.set_scene(scene)
+        base, st = gpu.render(cam, p)
+        assert np.array_equal(base, ref) and st.segments == st_ref.segments
+        for chunk in (1, 5, 37, 64):
+            gpu.set_option(R.OPT_CHUNK_LEN, chunk)
+            img, st = gpu.render(cam, p)
+            assert np.array_equal(img, ref) and st.camera_rays == 200 * 120 * 37, chunk
+        gpu.set_option(R.OPT_CHUNK_LEN, 4)
+        gpu.set_option(R.OPT_SAMPLE_BANK_GB, 0.003)          # ~3 MiB: forces several bands (one tile row is 25*10*64*4*12 B = 0.73 MiB)
         img, st = gpu.render(cam, p)
-        assert np.array_equal(img, ref) and st.camera_rays == 200 * 120 * 37, chunk
-    monkeypatch.delenv("RTW_CHUNK")
-    monkeypatch.setenv("RTW_SAMPLE_BUF_GB", "0.003")         # ~3 MiB: forces several bands (one tile row is 25*10*64*4*12 B = 0.73 MiB)
-    img, st = gpu.render(cam, p)
-    assert np.array_equal(img, ref) and st.segments == st_ref.segments
-    monkeypatch.setenv("RTW_SAMPLE_BUF_GB", "0.0005")        # less than one tile row: refused, not truncated
-    with pytest.raises(R.RtwError) as e:
-        gpu.render(cam, p)
-    assert e.value.status == -4
+        assert np.array_equal(img, ref) and st.segments == st_ref.segments
+        gpu.set_option(R.OPT_SAMPLE_BANK_GB, 0.0005)         # less than one tile row: refused, not truncated
+        with pytest.raises(R.RtwError) as e:
+            gpu.render(cam, p)
+        assert e.value.status == -4
+        with pytest.raises(R.RtwError):                      # unknown key / out-of-range value
+            gpu.set_option(99, 1)
+        with pytest.raises(R.RtwError):
+            gpu.set_option(R.OPT_CHUNK_LEN, 0)
 
 
 def test_example_program_through_the_c_abi(gpu, tmp_path):

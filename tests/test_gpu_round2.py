@@ -1,0 +1,259 @@
+"""Round-2 additions on the HIP path (through the C ABI): the native multi-GPU entry point, the C++ twin's dialect,
+the reference-held fixtures compared DIRECTLY with the GPU output, BVH depth bound, time-range guard, one block of the
+headline frame against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import rtw_amd as R
+from tests import oracle_binding as O
+from tests.test_oracle_golden import small_view, flag_params, GOLD
+from tests.test_abi_and_host import geometric_scene
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- rtw_mgpu: fork / ordered join of the row tasks over GPUs (Rust/src/viewport.rs:236-244) ------------------------
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], [0] * 5])
+def test_mgpu_contexts_on_one_gpu_reassemble_the_unsplit_frame(gpu, devices):
+    """N contexts (here all on GPU 0) render interleaved 8-row blocks and copy them straight into their image rows: the
+    frame is bit-identical to the one-context render; 54 rows = 6 full blocks + a ragged one of 6 rows."""
+    scene, cam, p = small_view(R.SCENE_C2, 96, 54, 4)
+    gpu.set_scene(scene)
+    full, st_full = gpu.render(cam, p)
+    with R.MultiRenderer(devices) as m:
+        m.set_scene(scene)
+        img, tot, per = m.render(cam, p)                                  # host frame
+        assert np.array_equal(img, full)
+        assert tot.segments == st_full.segments and tot.camera_rays == st_full.camera_rays and tot.rows == 54
+        assert sum(s.rows for s in per) == 54 and len(per) == len(devices)
+        assert [s.rows for s in per] == [R.lib().rtw_part_rows(54, 8, k, len(devices)) for k in range(len(devices))]
+        import torch
+        t = torch.full((54, 96, 3), -1.0, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        m.render(cam, p, out=t.data_ptr())                                # frame in GPU 0's HBM
+        assert np.array_equal(t.cpu().numpy(), full)
+        q = R.RtwParams.from_buffer_copy(p)                               # other block heights, incl. one that leaves devices idle
+        for rb in (1, 16, 64):
+            q.row_block = rb
+            img2, tot2, _ = m.render(cam, q)
+            assert np.array_equal(img2, full) and tot2.segments == st_full.segments, rb
+        q.row_block, q.part_index, q.part_count = 8, 0, 2                 # a partition of a partition is refused
+        with pytest.raises(R.RtwError):
+            m.render(cam, q)
+
+
+def test_mgpu_one_shot_and_headline_frame(gpu):
+    """rtw_render_multi_gpu (create / set scene / render / destroy) on C1, and three contexts on the headline frame
+    (1920 x 1080, reduced to 20 spp) against the one-context render."""
+    L = R.lib()
+    scene = R.Scene.generate(R.SCENE_C1)
+    cam, p = R.default_view(R.SCENE_C1)
+    gpu.set_scene(scene)
+    full, st = gpu.render(cam, p)
+    out = np.zeros_like(full)
+    per = (R.RtwStats * 3)()
+    dev = (C.c_int * 3)(0, 0, 0)
+    assert L.rtw_render_multi_gpu(dev, 3, C.byref(cam), C.byref(scene.pod), C.byref(p), out.ctypes.data_as(C.c_void_p), per) == 0
+    assert np.array_equal(out, full) and sum(s.segments for s in per) == st.segments
+    assert L.rtw_render_multi_gpu(dev, 3, C.byref(cam), C.byref(scene.pod), C.byref(p), None, per) == -1
+    bad = (C.c_int * 2)(0, 99)
+    assert L.rtw_render_multi_gpu(bad, 2, C.byref(cam), C.byref(scene.pod), C.byref(p), out.ctypes.data_as(C.c_void_p), None) == -2
+
+    scene = R.Scene.generate(R.SCENE_C2)
+    cam, p = R.default_view(R.SCENE_C5)
+    cam.shutter, p.samples = 0.0, 20
+    gpu.set_scene(scene)
+    full, st = gpu.render(cam, p)
+    with R.MultiRenderer([0, 0, 0]) as m:
+        m.set_scene(scene)
+        img, tot, _ = m.render(cam, p)
+    assert np.array_equal(img, full) and tot.segments == st.segments and tot.camera_rays == 1920 * 1080 * 20
+
+
+# ---- a11: the C++ twin's dialect on the device ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,mat,flags", [("control", R.METALLIC_M, 0), ("glass", R.GLASS_M, R.FLAG_CPP_DIELECTRIC),
+                                            ("glass", R.GLASS_M, R.FLAG_CPP)])
+def test_s_test_images_on_the_gpu(gpu, name, mat, flags):
+    """The reference's own parity definition (identical 8-bit images of an RNG-free scene, glass_tests.rs:146-193) with the
+    HIP path on one side: both 300 x 200 s_test images (C++/src/tests.cpp:275-294) reproduced pixel for pixel."""
+    z = np.load(os.path.join(GOLD, "s_test.npz"))
+    h, w = [int(x) for x in z[name + "_shape"]]
+    want = np.unpackbits(z[name + "_bits"])[: h * w].reshape(h, w).astype(bool)
+    scene = R.Scene([R.Sphere.new((0.0, 0.0, -1.0), 0.5, (1.0, 1.0, 1.0), mat),
+                     R.Sphere.with_albedo((0.0, -100.5, -1.0), 100.0, (0.8, 0.5, 1.0), R.SCATTER_M)])
+    cam, hh = O.viewport_new(300, 1.5)
+    assert hh == h
+    p = flag_params(flags=flags)
+    p.width, p.height = w, h
+    gpu.set_scene(scene)
+    for accel in (R.ACCEL_BRUTE, R.ACCEL_BVH):
+        p.accel = accel
+        img, _ = gpu.render(cam, p)
+        q = (255.0 * img.astype(np.float64)).astype(np.int32)         # RGB_int: static_cast<int>(255 * c) RGB.cpp:16-20
+        yellow = (q == np.array([255, 255, 0])).all(axis=2)
+        blue = (q == np.array([0, 0, 255])).all(axis=2)
+        assert (yellow | blue).all()
+        assert int((yellow != want).sum()) == 0
+
+
+def test_cerr_trace_pixels_on_the_gpu(gpu):
+    """Rust/cerr (the 10 x 10 glass scene of an older C++ build): the pixels whose paths the trace shows ending in the
+    sky / on the ground, rendered by the GPU with the deterministic dielectric, agree with the oracle bit for bit and are
+    blue / yellow exactly where the trace's last record says sky / scatter."""
+    import json
+    data = json.load(open(os.path.join(GOLD, "cerr_trace.json")))
+    scene = R.Scene([R.Sphere.new((0.0, 0.0, -1.0), 0.5, (1.0, 1.0, 1.0), R.GLASS_M),
+                     R.Sphere.new((0.0, -100.5, -1.0), 100.0, (1.0, 1.0, 1.0), R.EMPTY_M)])
+    # the old camera: dir = (-1 + 2u, -1 + 2v, -1), u = x/9, v = (9-y)/9  ==  pixel00 + x du + y dv
+    cam = R.RtwCamera()
+    f = np.float32
+    for k, v in enumerate((-1.0, 1.0, -1.0)):
+        cam.pixel00[k] = v
+    cam.delta_u[0] = float(f(2) / f(9))
+    cam.delta_v[1] = -float(f(2) / f(9))
+    p = flag_params(flags=R.FLAG_CPP_DIELECTRIC)
+    p.gamma = 1.0
+    ref, _ = O.render(cam, scene, p, threads=1)
+    gpu.set_scene(scene)
+    img, _ = gpu.render(cam, p)
+    assert np.array_equal(img, ref)
+    checked = 0
+    for px in data["pixels"]:
+        last = px["bounces"][-1]["kind"]
+        got = tuple(img[px["y"], px["x"]])
+        assert got == ((0.0, 0.0, 1.0) if last == "sky" else (1.0, 1.0, 0.0)), px
+        checked += 1
+    assert checked == 58
+
+
+def test_cpp_dialect_bit_exact_and_statistical(gpu):
+    """RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE on the HIP path == the oracle bit for bit (both closest-hit
+    strategies), and -- where oracle/_ref exists -- statistically == the reference's own C++ objects."""
+    glass = R.Sphere.with_albedo((-1.0, 0.0, -1.0), 0.5, (1, 1, 1), R.GLASS_M)
+    scene = R.Scene.generate(R.SCENE_METAL_TEST)
+    spheres = [scene._spheres[i] for i in range(scene.n_spheres)] + [glass.pod]
+    scene = R.Scene(spheres)
+    cam, h = O.viewport_new(96, np.float32(96) / np.float32(54))
+    cam.lens_radius = 0.01
+    p = flag_params(depth=10, flags=R.FLAG_CPP)
+    p.width, p.height, p.samples, p.integrator, p.sampler, p.gamma = 96, 54, 192, R.INTEGRATOR_GRADIENT, R.SAMPLER_ROW, 1.0
+    ref, st_ref = O.render(cam, scene, p, threads=16)
+    gpu.set_scene(scene)
+    imgs = {}
+    for accel in (R.ACCEL_BRUTE, R.ACCEL_BVH):
+        p.accel = accel
+        img, st = gpu.render(cam, p)
+        assert st.segments == st_ref.segments
+        assert np.array_equal(img, ref), accel
+        imgs[accel] = img
+    p.flags = 0
+    plain, _ = gpu.render(cam, p)
+    assert not np.array_equal(plain, ref)
+    if O.have_ref():
+        p.flags = R.FLAG_CPP
+        b, seg, _ = O.ref_render(cam, scene, p, rand_seed=5)
+
+        def blocks(x):
+            return x[:54, :96].reshape(9, 6, 16, 6, 3).mean(axis=(1, 3))
+        da = blocks(imgs[R.ACCEL_BVH].astype(np.float64)) - blocks(b)
+        assert abs(da.mean()) < 2e-3 and np.abs(da).max() < 0.05, (da.mean(), np.abs(da).max())
+
+
+def test_rust2_integrator_honours_cpp_dielectric(gpu):
+    from tests.test_oracle_golden import rust2_view
+    scene, cam, p = rust2_view(samples=16)
+    p.flags, p.gamma = R.FLAG_CPP_DIELECTRIC, 1.0
+    ref, st_ref = O.render(cam, scene, p)
+    gpu.set_scene(scene)
+    img, st = gpu.render(cam, p)
+    assert st.segments == st_ref.segments and np.array_equal(img, ref)
+
+
+# ---- Vec3::rotated known answers (vec3.rs:363-404) through the GPU ---------------------------------------------------------
+@pytest.mark.parametrize("rot,want", [((np.pi / 6, 0.0, 0.0), (1.0, 0.0, -0.0)), ((0.0, 0.0, np.pi / 6), None)])
+def test_rotated_known_answers_on_the_gpu(gpu, rot, want):
+    """An instance holding a quad with normal (1, 0, 0), rotated by the reference's test rotations; the NORMAL integrator
+    returns (rotated(normal) + 1) / 2, so the image exposes Vec3::rotated as the device applies it."""
+    rot = tuple(float(np.float32(x)) for x in rot)
+    inst = R.Instance.new_quads([R.Quad.new((3, -50, -50), (0, 100, 0), (0, 0, 100), R.SCATTER_M, (1, 1, 1))])
+    inst.rotate(rot)
+    scene = R.Scene.new([], [], [inst])
+    cam, h = O.viewport_new(32, np.float32(32) / np.float32(18), origin=(0, 0, 0), direction=(1, 0, 0))
+    p = flag_params(depth=2)
+    p.width, p.height, p.samples, p.integrator, p.sampler, p.gamma = 32, 18, 1, R.INTEGRATOR_NORMAL, R.SAMPLER_NO_RAND, 1.0
+    ref, _ = O.render(cam, scene, p)
+    gpu.set_scene(scene)
+    for accel in (R.ACCEL_BRUTE, R.ACCEL_BVH):
+        p.accel = accel
+        img, st = gpu.render(cam, p)
+        assert np.array_equal(img, ref)
+    n = img[9, 16].astype(np.float64) * 2.0 - 1.0
+    if want is None:
+        want = (np.cos(np.float32(rot[2])), np.sin(np.float32(rot[2])), 0.0)          # vec3.rs:385-391
+    assert np.abs(n - np.array(want, np.float64)).max() < 2e-7, (n, want)
+    assert np.abs(n - R.vec3_rotated((1, 0, 0), rot)).max() < 1.2e-7
+
+
+# ---- ADVICE r1 ---------------------------------------------------------------------------------------------------------------
+def test_skewed_scene_stays_inside_the_device_stack(gpu):
+    """400 equal spheres at x = 1.2^i used to build a depth-27 tree and overflow the 24-level LDS stack."""
+    sc = geometric_scene(400, 1.2)
+    cam, h = O.viewport_new(96, np.float32(96) / np.float32(54), origin=(20.0, 0.5, 8.0), direction=(0.2, -0.03, -1.0), vfov=70.0)
+    p = flag_params(depth=6)
+    p.width, p.height, p.samples, p.integrator, p.sampler, p.gamma = 96, 54, 8, R.INTEGRATOR_GRADIENT, R.SAMPLER_ROW, 1.0
+    ref, st_ref = O.render(cam, sc, p, threads=16)
+    gpu.set_scene(sc)
+    for flags in (0, R.FLAG_GLOBAL_NODES):
+        p.accel, p.flags = R.ACCEL_BVH, flags
+        img, st = gpu.render(cam, p)
+        assert st.segments == st_ref.segments and np.array_equal(img, ref), flags
+        assert st.node_tests > 0
+
+
+def test_moving_scene_outside_the_built_time_range(gpu):
+    """The BVH bounds cover the ray.time range given to rtw_ctx_set_scene; a render outside it must not prune with them."""
+    scene, cam, p = small_view(R.SCENE_C5, 96, 54, 8)
+    p.gamma = 1.0
+    cam.time0, cam.shutter = 2.0, 0.5                      # the moving spheres have long left their t in [0, 1/30] boxes
+    ref, st_ref = O.render(cam, scene, p, threads=16)
+    gpu.set_scene(scene, 0.0, 1.0 / 30.0)                  # built for frame 0
+    p.accel = R.ACCEL_BVH
+    img, st = gpu.render(cam, p)
+    assert st.segments == st_ref.segments and st.node_tests == 0          # demoted to the list walk
+    assert (np.abs(img - ref).max(axis=2) > 0).sum() <= 0.002 * 96 * 54       # (textured ground: atan2f / acosf texel edges)
+    gpu.set_scene(scene, 2.0, 2.5)
+    img2, st2 = gpu.render(cam, p)
+    assert st2.node_tests > 0 and np.array_equal(img2, img)
+
+
+def test_small_scenes_walk_the_list(rtw):
+    """RTW_OPT_LIST_WALK_MAX: a BVH request on a handful of spheres runs the list-walk kernel (same image)."""
+    scene = R.Scene.generate(R.SCENE_C1)
+    cam, p = R.default_view(R.SCENE_C1)
+    p.accel = R.ACCEL_BVH
+    with rtw.Renderer(0) as r:
+        r.set_scene(scene)
+        a, sa = r.render(cam, p)
+        assert sa.node_tests == 0                                        # default: 3 spheres are below the crossover
+        r.set_option(R.OPT_LIST_WALK_MAX, 0)
+        b, sb = r.render(cam, p)
+        assert sb.node_tests > 0 and np.array_equal(a, b) and sa.segments == sb.segments
+
+
+# ---- the headline frame against the oracle -------------------------------------------------------------------------------------
+def test_c3_one_block_against_the_oracle(gpu):
+    """BASELINE config 3 (1920 x 1080 x 500 spp, depth 50): one 8-row block through the sphere field (rows 600..607,
+    7.7 M camera rays) against the oracle -- bit for bit at gamma 1, <= 2 ulp (powf) at the reference's gamma 2."""
+    scene = R.Scene.generate(R.SCENE_C2)
+    cam, p = R.default_view(R.SCENE_C5)
+    cam.shutter = 0.0
+    p.row_block, p.part_index, p.part_count = 8, 75, 135            # block 75 = rows 600..607
+    p.gamma = 1.0
+    ref, st_ref = O.render(cam, scene, p, threads=16)
+    gpu.set_scene(scene)
+    img, st = gpu.render(cam, p)
+    assert st.rows == 8 and st.camera_rays == 8 * 1920 * 500 and st.segments == st_ref.segments
+    assert np.array_equal(img, ref)

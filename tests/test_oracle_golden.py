@@ -382,3 +382,56 @@ def test_rust2_ray_color_semantics():
     assert sa.segments == sc.segments
     np.testing.assert_allclose(a, c, rtol=3e-6, atol=1e-7)
     assert a[..., 0].max() > a[..., 2].min()      # the emissive red sphere shows
+
+
+# ---- 10. the C++ twin's dialect: RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE ------------------
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (only exists where /root/reference does)")
+def test_oracle_cpp_dialect_vs_reference_objects_statistical():
+    """metal_test's four spheres (C++/src/tests.cpp:195-212: lambert, mirror, FUZZY3 = 0.7) rendered by the reference's own
+    C++ objects and by the oracle with the C++ dialect flags: the fuzzy sphere is where the dialects differ (C++ normalises the
+    diffuse and the mirror direction before the lerp, C++/src/materials.cpp:4-13; Rust does not, materials.rs:141-149)."""
+    scene = R.Scene.generate(R.SCENE_METAL_TEST)
+    cam, h = O.viewport_new(96, np.float32(96) / np.float32(54))
+    p = flag_params(depth=10, flags=R.FLAG_CPP)
+    p.width, p.height, p.samples, p.integrator, p.sampler, p.gamma = 96, 54, 192, R.INTEGRATOR_GRADIENT, R.SAMPLER_ROW, 1.0
+    a, sa = O.render(cam, scene, p)
+    b, seg, _ = O.ref_render(cam, scene, p, rand_seed=11)
+
+    def blocks(x):
+        return x[:54, :96].reshape(9, 6, 16, 6, 3).mean(axis=(1, 3))
+    da = blocks(a.astype(np.float64)) - blocks(b)
+    assert abs(da.mean()) < 2e-3, da.mean()
+    assert np.abs(da).max() < 0.05, np.abs(da).max()
+    assert abs(sa.segments / sa.camera_rays - seg / sa.camera_rays) < 0.02
+    # the flags do change the paths (same seed, different image), and only through the documented branches:
+    p.flags = 0
+    c, _ = O.render(cam, scene, p)
+    assert not np.array_equal(a, c)
+    p.flags = R.FLAG_CPP_DIELECTRIC                       # no dielectric in this scene: that flag alone changes nothing
+    d, _ = O.render(cam, scene, p)
+    assert np.array_equal(c, d)
+
+
+def test_cpp_diffuse_known_answers():
+    """One lambert bounce under RTW_FLAG_CPP_DIFFUSE: the scattered direction is a UNIT vector (C++ normalises
+    (point + normal + rand_unit) - point), under the Rust rule it is normal + rand_unit (length in [0, 2])."""
+    scene = R.Scene([R.Sphere.with_albedo((0, 0, -1), 0.5, (0.5, 0.5, 0.5), R.SCATTER_M)])
+    p = flag_params(depth=1)
+    p.integrator = R.INTEGRATOR_GRADIENT
+    lens = {0: [], R.FLAG_CPP_DIFFUSE: []}
+    for flags in lens:
+        p.flags = flags
+        for s in range(64):
+            b, _ = O.trace_ray((0, 0, 0), (0.05, 0.02, -1.0), 0.0, scene, p, pixel=3, sample=s)
+            assert b[0].hit == 1
+            lens[flags].append(float(np.linalg.norm(np.array(b[0].next_dir, np.float64))))
+    assert np.allclose(lens[R.FLAG_CPP_DIFFUSE], 1.0, atol=3e-7)
+    assert np.std(lens[0]) > 0.1 and max(lens[0]) <= 2.0 + 1e-6
+    # a mirror: Rust reflects unit(d) (already unit), C++ normalises once more -- both unit, both the mirror direction
+    scene = R.Scene([R.Sphere.with_albedo((0, 0, -1), 0.5, (1, 1, 1), R.METALLIC_M)])
+    dirs = []
+    for flags in (0, R.FLAG_CPP_DIFFUSE):
+        p.flags = flags
+        b, _ = O.trace_ray((0, 0, 0), (0.05, 0.02, -1.0), 0.0, scene, p)
+        dirs.append(np.array(b[0].next_dir, np.float64))
+    assert np.abs(dirs[0] - dirs[1]).max() < 3e-7 and abs(np.linalg.norm(dirs[1]) - 1.0) < 3e-7
