@@ -8,6 +8,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Load order matters on ROCm: PyTorch bundles its own copy of the HIP runtime, librtw_hip.so links the system one
+# (/opt/rocm).  When torch is imported first the dynamic linker hands librtw_hip.so the runtime that is already loaded (same
+# soname) and both share one; the other way round torch brings up a SECOND runtime in the process, whose device enumeration
+# fails ("No HIP GPUs are available", gpurun_out/r02_debug_torch.log).  Tests that hand torch tensors to the library
+# (device output pointers, bench rehearsals) therefore need torch loaded before the first rtw call.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is plumbing for a few tests only
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

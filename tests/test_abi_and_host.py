@@ -340,9 +340,13 @@ def test_multi_gpu_entry_points_without_a_device():
     assert L.rtw_mgpu_render(None, C.byref(cam), C.byref(p), out.ctypes.data_as(C.c_void_p), None, None) == -1
 
 
-def geometric_scene(n=400, ratio=1.2):
-    """Equal spheres at x = ratio^i: every SAH split peels a few spheres off the dense end (depth 27)."""
-    return R.Scene([R.Sphere.with_albedo((float(np.float32(ratio) ** i), 0.0, -5.0), 0.01, (0.5, 0.5, 0.5)) for i in range(n)])
+def geometric_scene(n=400, ratio=1.2, rel_radius=None):
+    """Spheres at x = ratio^i: every SAH split peels a few spheres off the dense end (equal spheres, n = 400,
+    ratio 1.2 built a tree of depth 27).  rel_radius: radius = rel_radius * x (visible from a camera near the dense end)."""
+    f = np.float32
+    mats = [R.SCATTER_M, R.METALLIC_M, R.GLASS_M]
+    return R.Scene([R.Sphere.with_albedo((float(f(ratio) ** i), 0.0, -5.0), 0.01 if rel_radius is None else float(f(rel_radius) * f(ratio) ** i),
+                                         (0.5, 0.5, 0.5), mats[i % 3]) for i in range(n)])
 
 
 @pytest.mark.parametrize("n,ratio", [(400, 1.2), (3000, 1.01), (64, 4.0), (1000, 1.05)])

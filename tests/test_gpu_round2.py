@@ -199,12 +199,16 @@ def test_rotated_known_answers_on_the_gpu(gpu, rot, want):
 
 # ---- ADVICE r1 ---------------------------------------------------------------------------------------------------------------
 def test_skewed_scene_stays_inside_the_device_stack(gpu):
-    """400 equal spheres at x = 1.2^i used to build a depth-27 tree and overflow the 24-level LDS stack."""
-    sc = geometric_scene(400, 1.2)
-    cam, h = O.viewport_new(96, np.float32(96) / np.float32(54), origin=(20.0, 0.5, 8.0), direction=(0.2, -0.03, -1.0), vfov=70.0)
+    """Spheres at x = 1.2^i (the old "SAH until depth 20" rule built depth 27 and overflowed the 24-level LDS
+    stack): the tree now stops at depth 24 exactly, and both node variants return the list walk's image."""
+    sc = geometric_scene(200, 1.2, rel_radius=0.12)
+    depth = C.c_uint32()
+    assert R.lib().rtw_bvh_validate(C.byref(sc.pod), 0.0, 0.0, None, C.byref(depth), None, None) == 0 and depth.value == 24
+    cam, h = O.viewport_new(96, np.float32(96) / np.float32(54), origin=(6.0, 0.3, 2.0), direction=(0.3, -0.03, -1.0), vfov=80.0)
     p = flag_params(depth=6)
     p.width, p.height, p.samples, p.integrator, p.sampler, p.gamma = 96, 54, 8, R.INTEGRATOR_GRADIENT, R.SAMPLER_ROW, 1.0
     ref, st_ref = O.render(cam, sc, p, threads=16)
+    assert st_ref.segments > 1.1 * st_ref.camera_rays
     gpu.set_scene(sc)
     for flags in (0, R.FLAG_GLOBAL_NODES):
         p.accel, p.flags = R.ACCEL_BVH, flags
