@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-nodes", action="store_true", help="A/B: BVH nodes in global memory (f32) instead of LDS (f16)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (INVALID as a benchmark; for smoke runs)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="rtw_ctx_set_option, e.g. --opt 4=5 (RTW_OPT_BLOCKS_PER_CU = 5) or --opt 6=1 (one path per lane); A/B runs")
     ap.add_argument("--devices", default="", help="single-process rtw_mgpu over these HIP ordinals, e.g. 0,0,0 = three contexts on one GPU "
                                                   "(a rehearsal of the N-GPU path on a 1-GPU box: INVALID as a benchmark)")
     args = ap.parse_args()
@@ -123,6 +125,8 @@ def main():
         args.gpus = len(devices)
         r = R.MultiRenderer(devices)              # fork / ordered join of viewport.rs:236-244 over GPUs, no torch.distributed
         r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
+        for kv in args.opt:
+            r.set_option(int(kv.split("=")[0]), float(kv.split("=")[1]))
         frame_buf = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
         torch.cuda.synchronize(dev)
 
@@ -133,6 +137,8 @@ def main():
         r = R.Renderer(local_rank)                                  # one rtw_ctx per process == per GPU
         r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
+        for kv in args.opt:
+            r.set_option(int(kv.split("=")[0]), float(kv.split("=")[1]))
         local = torch.zeros((par.max_rows(H, world), W, 3), dtype=torch.float32, device=dev)
 
         def render_rows(row_block, idx, cnt, out):
@@ -154,14 +160,14 @@ def main():
     fence()
     t0 = time.perf_counter()
     seg = rays = nodes = tests = 0
-    steps3, lanes3 = [0, 0, 0], [0, 0, 0]
+    steps3, lanes3 = [0] * 5, [0] * 5
     kernel_ms = 0.0
     frame = None
     for _ in range(args.steps):
         frame, st = step()
         seg += st.segments; rays += st.camera_rays; nodes += st.node_tests; tests += st.sphere_tests
         kernel_ms += st.kernel_ms
-        for k in range(3):
+        for k in range(5):
             steps3[k] += st.phase_steps[k]; lanes3[k] += st.phase_lanes[k]
     fence()
     elapsed = time.perf_counter() - t0
@@ -199,7 +205,7 @@ def main():
                          "algorithmic_flop_per_launch": flop,
                          "scheduler_census_rank0": {n: {"wave_steps": steps3[k] // args.steps,
                                                             "simd_efficiency": round(lanes3[k] / max(1, 64 * steps3[k]), 4)}
-                                                        for k, n in enumerate(("traverse", "leaf", "shade"))},
+                                                        for k, n in enumerate(("traverse", "leaf", "shade", "switch", "new_path")) if steps3[k]},
                          "units_per_launch": {"segments": seg / args.steps / world, "node_visits": nodes / args.steps / world,
                                               "sphere_tests": tests / args.steps / world},
                          "hbm": {"achieved": round((H * W * 12 + rays / args.steps * 24) / world / k_s / 1e9, 3), "peak": 8000.0, "unit": "GB/s",

@@ -38,12 +38,13 @@ pub struct RtwParams { pub width: u32, pub height: u32, pub samples: u32, pub de
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]
 pub struct RtwStats { pub camera_rays: u64, pub segments: u64, pub sphere_tests: u64, pub node_tests: u64,
     pub nan_pixels: u32, pub rows: u32, pub kernel_ms: f32, pub total_ms: f32,
-    pub phase_steps: [u64; 3], pub phase_lanes: [u64; 3], pub quad_tests: u64 }
+    pub phase_steps: [u64; 6], pub phase_lanes: [u64; 6], pub quad_tests: u64 }
 
 #[repr(C)] pub struct RtwCtx { _private: [u8; 0] }
+#[repr(C)] pub struct RtwMgpu { _private: [u8; 0] }
 
 #[repr(u32)] #[derive(Clone, Copy)]
-pub enum Integrator { Gradient = 0, BgColor = 1, Normal = 2, Flag = 3 }   // ray_color.rs:12-92
+pub enum Integrator { Gradient = 0, BgColor = 1, Normal = 2, Flag = 3, Rust2 = 4 }   // ray_color.rs:12-92; Rust2/src/viewport/ray_color.rs:12-37
 #[repr(u32)] #[derive(Clone, Copy)]
 pub enum Sampler { Row = 0, Stratified = 1, Centres = 2, NoRand = 3 }      // viewport.rs:270-305, 430-516
 
@@ -55,6 +56,12 @@ extern "C" {
     fn rtw_ctx_render_multi(ctx: *mut RtwCtx, cam: *const RtwCamera, p: *const RtwParams, fps: f32, start_frame: u32, n_frames: u32,
                             out_rgb: *mut c_void, st: *mut RtwStats) -> i32;
     fn rtw_strerror(status: i32) -> *const std::os::raw::c_char;
+    fn rtw_part_rows(height: u32, row_block: u32, part_index: u32, part_count: u32) -> u32;
+    fn rtw_mgpu_create(devices: *const i32, n: u32, out: *mut *mut RtwMgpu) -> i32;
+    fn rtw_mgpu_destroy(m: *mut RtwMgpu);
+    fn rtw_mgpu_set_scene(m: *mut RtwMgpu, scene: *const RtwScene, t_begin: f32, t_end: f32) -> i32;
+    fn rtw_mgpu_render(m: *mut RtwMgpu, cam: *const RtwCamera, p: *const RtwParams, out_rgb: *mut c_void,
+                       per_device: *mut RtwStats, total: *mut RtwStats) -> i32;
 }
 
 #[derive(Debug)]
@@ -99,7 +106,9 @@ impl Renderer {
     }
     /// -> `Img`-shaped rows ([height][width] of Rgb<f32>), gamma-corrected, unclamped (viewport.rs:301).
     pub fn render(&mut self, cam: &RtwCamera, p: &RtwParams) -> Result<(Vec<Vec<[f32; 3]>>, RtwStats), RtwError> {
-        let mut flat = vec![[0f32; 3]; (p.width as usize) * (p.height as usize)];
+        // a row partition (RtwParams.part_count > 1) returns only the rows it owns, compactly
+        let rows = unsafe { rtw_part_rows(p.height, p.row_block, p.part_index, p.part_count) } as usize;
+        let mut flat = vec![[0f32; 3]; (p.width as usize) * rows];
         let mut st = RtwStats::default();
         check(unsafe { rtw_ctx_render(self.ctx, cam, p, flat.as_mut_ptr() as *mut c_void, &mut st) })?;
         let rows = flat.chunks(p.width as usize).take(st.rows as usize).map(|r| r.to_vec()).collect();
@@ -117,6 +126,28 @@ impl Renderer {
     }
 }
 impl Drop for Renderer { fn drop(&mut self) { unsafe { rtw_ctx_destroy(self.ctx) } } }
+
+/// All GPUs of a node from one host thread: the fork / ordered join of `async_render`'s row tasks
+/// (viewport.rs:236-244; rayon: Rust2/src/viewport.rs:119-122) with GPUs in place of worker threads.  The host owns the
+/// frame (`Img`); every GPU copies its interleaved 8-row blocks straight into their image rows.
+pub struct MultiRenderer { m: *mut RtwMgpu, n: usize }
+impl MultiRenderer {
+    pub fn new(devices: &[i32]) -> Result<Self, RtwError> {
+        let mut m = std::ptr::null_mut();
+        check(unsafe { rtw_mgpu_create(devices.as_ptr(), devices.len() as u32, &mut m) })?;
+        Ok(Self { m, n: devices.len() })
+    }
+    pub fn set_scene(&mut self, sc: &RtwScene, t_begin: f32, t_end: f32) -> Result<(), RtwError> {
+        check(unsafe { rtw_mgpu_set_scene(self.m, sc, t_begin, t_end) })
+    }
+    pub fn render(&mut self, cam: &RtwCamera, p: &RtwParams) -> Result<(Vec<Vec<[f32; 3]>>, Vec<RtwStats>), RtwError> {
+        let mut flat = vec![[0f32; 3]; (p.width as usize) * (p.height as usize)];
+        let mut per = vec![RtwStats::default(); self.n];
+        check(unsafe { rtw_mgpu_render(self.m, cam, p, flat.as_mut_ptr() as *mut c_void, per.as_mut_ptr(), std::ptr::null_mut()) })?;
+        Ok((flat.chunks(p.width as usize).map(|r| r.to_vec()).collect(), per))
+    }
+}
+impl Drop for MultiRenderer { fn drop(&mut self) { unsafe { rtw_mgpu_destroy(self.m) } } }
 
 // In the reference crate, next to `impl Viewport` (viewport.rs:307):
 //

@@ -217,10 +217,10 @@ typedef struct RtwStats {
     uint32_t rows;           /* rows written by this call                             */
     float    kernel_ms;      /* device time of the render kernels (hipEvent)          */
     float    total_ms;       /* host wall time of the call                            */
-    /* BVH kernel scheduler census: wave-level steps executed per phase (0 traverse, 1 leaf, 2 shade)
-     * and the lanes that were live in them; lanes / (64 * steps) is the SIMD efficiency of a phase. */
-    uint64_t phase_steps[3];
-    uint64_t phase_lanes[3];
+    /* BVH kernel scheduler census: wave-level steps executed per phase (0 traverse, 1 leaf, 2 shade; 3..5 reserved for
+     * experimental phases) and the lanes that were live in them; lanes / (64 * steps) is the SIMD efficiency of a phase. */
+    uint64_t phase_steps[6];
+    uint64_t phase_lanes[6];
     uint64_t quad_tests;     /* ray/quad plane tests (top-level quads and instance members) */
 } RtwStats;
 

@@ -4,6 +4,7 @@
 #include "rtw_host.h"
 
 #define RTW_BLOCK 256   // 4 waves per workgroup
+#define RTW_N_STATS 32  // 64-bit counters a render launch accumulates (KArgs.stats)
 #ifndef RTW_LIST_WALK_MAX_DEFAULT
 #define RTW_LIST_WALK_MAX_DEFAULT 8u   // RTW_OPT_LIST_WALK_MAX: scenes this small walk the list even when the BVH is asked for
 #endif
@@ -54,7 +55,7 @@ struct KArgs {
     float bg[3];
     float *out;                   // [rows of the partition][width][3]
     uint32_t *queue;              // work-item counter, zeroed before launch
-    unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels [5..7] phase steps [8..10] phase lanes [14] quad tests
+    unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels [5..7] phase steps [8..10] phase lanes [14] quad tests [16..19] steps, lanes of phases 3 (switch), 4 (new path)
 };
 
 // accel: RTW_ACCEL_BRUTE, RTW_ACCEL_BVH; the BVH launch picks the LDS-resident variant when a.bvh.nodes16 != null

@@ -55,6 +55,7 @@ struct rtw_ctx {
     int opt_lds_geom = -1;
     uint32_t opt_blocks_per_cu = 0;
     uint32_t opt_list_walk_max = RTW_LIST_WALK_MAX_DEFAULT;
+
     // caches of per-call driver queries (each costs tens of microseconds: visible on small frames)
     std::map<std::pair<const void *, uint32_t>, uint32_t> occupancy;    // (kernel, dynamic LDS bytes) -> resident workgroups per CU
     const void *attr_ptr = nullptr; bool attr_on_device = false; int attr_device = -1;   // last out_rgb classified
@@ -165,8 +166,8 @@ int rtw_ctx_create(int device, rtw_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 64);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_stats, 16 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stats, 16 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_stats, RTW_N_STATS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stats, RTW_N_STATS * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) { g_last_hip = (int)e; rtw_ctx_destroy(c); return RTW_E_HIP; }
     c->stream = c->own_stream;
     *out = c;
@@ -464,7 +465,7 @@ static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, 
         per_cu = it->second;
     }
 
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, RTW_N_STATS * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (uint32_t tr0 = 0; tr0 < tile_rows || tr0 == 0; tr0 += (uint32_t)band_tile_rows) {
         const uint32_t tr1 = tr0 + (uint32_t)band_tile_rows < tile_rows ? tr0 + (uint32_t)band_tile_rows : tile_rows;
@@ -480,7 +481,7 @@ static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, 
         if (tile_rows == 0) break;
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, RTW_N_STATS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     if (out.scatter) {
         if (!direct) { int rc = scatter_rows(c, c->d_out, out.base, p->width, p->height, a.row_block, p->part_index, p->part_count); if (rc != RTW_OK) return rc; }
     } else if (!direct) HIP_TRY(hipMemcpyAsync(out.base, c->d_out, out_bytes, hipMemcpyDefault, c->stream));
@@ -505,6 +506,7 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
         stats->quad_tests = h_stats[14];
         stats->kernel_ms = ms;
         for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
+        for (int k = 3; k < 5; k++) { stats->phase_steps[k] = h_stats[16 + 2 * (k - 3)]; stats->phase_lanes[k] = h_stats[17 + 2 * (k - 3)]; }
 #if defined(RTW_STAMP) || defined(RTW_ENDTIMES)     // diagnostic builds only (scripts/gpu_endtimes.py)
         if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu\n", h_stats[11], h_stats[12], h_stats[13]);
         if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15]) {   // RTW_ENDTIMES build: [12] longest wave lifetime [13] sum of wave lifetimes [15] waves
@@ -610,7 +612,7 @@ int rtw_mgpu_render(rtw_mgpu *m, const RtwCamera *cam, const RtwParams *params, 
         if (per_device) per_device[k] = st;
         sum.camera_rays += st.camera_rays; sum.segments += st.segments; sum.sphere_tests += st.sphere_tests;
         sum.node_tests += st.node_tests; sum.quad_tests += st.quad_tests; sum.nan_pixels += st.nan_pixels; sum.rows += st.rows;
-        for (int i = 0; i < 3; i++) { sum.phase_steps[i] += st.phase_steps[i]; sum.phase_lanes[i] += st.phase_lanes[i]; }
+        for (int i = 0; i < 6; i++) { sum.phase_steps[i] += st.phase_steps[i]; sum.phase_lanes[i] += st.phase_lanes[i]; }
         if (st.kernel_ms > sum.kernel_ms) sum.kernel_ms = st.kernel_ms;
     }
     sum.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -40,7 +40,7 @@ def test_pod_sizes_match_header():
     assert C.sizeof(R.RtwSphere) == 80
     assert C.sizeof(R.RtwTexture) == 16
     assert C.sizeof(R.RtwParams) == 72
-    assert C.sizeof(R.RtwStats) == 104
+    assert C.sizeof(R.RtwStats) == 152
     assert C.sizeof(R.RtwScene) == 96
     assert C.sizeof(R.RtwQuad) == 88
     assert C.sizeof(R.RtwInstance) == 48
