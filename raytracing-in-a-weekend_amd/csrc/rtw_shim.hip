@@ -472,7 +472,16 @@ static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, 
         a.k_base = tr0 * 8; a.k_end = tr1 * 8 < n_rows ? tr1 * 8 : n_rows;
         a.n_tiles = a.tiles_x * (tr1 - tr0);
         a.total_work = a.n_tiles * a.n_chunks * 64u;              // < 2^32 by the item bound above
-        uint32_t grid = (uint32_t)c->n_cu * per_cu;
+        // Small launches are latency-bound, not throughput-bound: a lane should own >= ~16 work units before another resident
+        // workgroup per CU pays (gpurun_out/r02_small_frame.log: C1 0.494 -> 0.276 ms with 1 workgroup per CU instead of 6, `First
+        // frame` 3.15 -> 2.68 ms with 4; the 1080p frames are indifferent).  An explicit RTW_OPT_BLOCKS_PER_CU wins.
+        uint32_t wg_per_cu = per_cu;
+        if (c->opt_blocks_per_cu == 0) {
+            const uint64_t lanes_per_wg_row = (uint64_t)c->n_cu * RTW_BLOCK * 16ull;
+            const uint64_t want = ((uint64_t)a.total_work + lanes_per_wg_row - 1) / lanes_per_wg_row;
+            if (want < wg_per_cu) wg_per_cu = (uint32_t)(want ? want : 1);
+        }
+        uint32_t grid = (uint32_t)c->n_cu * wg_per_cu;
         const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
         if (grid > need) grid = need ? need : 1;
         HIP_TRY(hipMemsetAsync(c->d_queue, 0, 64, c->stream));

@@ -1,4 +1,5 @@
-"""Time every BASELINE config at full size with both closest-hit strategies (one GPU); prints a markdown table."""
+"""Time every BASELINE config at full size with both closest-hit strategies (one GPU); prints a markdown table.
+Columns: BVH request as shipped (small scenes are routed to the list walk, RTW_OPT_LIST_WALK_MAX), BVH forced (option 0), list walk."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,14 +18,15 @@ for name, scene_id, view_id, shutter in cfgs:
     out = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device="cuda:0")
     r.set_scene(sc, cam.time0, cam.time0 + cam.shutter)
     res = {}
-    for accel in (R.ACCEL_BVH, R.ACCEL_BRUTE):
-        p.accel = accel
+    for accel in (R.ACCEL_BVH, "tree", R.ACCEL_BRUTE):
+        r.set_option(R.OPT_LIST_WALK_MAX, 0 if accel == "tree" else 8)
+        p.accel = R.ACCEL_BVH if accel == "tree" else accel
         r.render(cam, p, out=out.data_ptr())
         best = None
         for _ in range(3):
             _, st = r.render(cam, p, out=out.data_ptr())
             if best is None or st.kernel_ms < best.kernel_ms: best = st
         res[accel] = best
-    b, f = res[R.ACCEL_BVH], res[R.ACCEL_BRUTE]
+    b, f, t = res[R.ACCEL_BVH], res[R.ACCEL_BRUTE], res["tree"]
     print(f"| {name} | {sc.n_spheres}+{sc.n_quads}q+{sc.n_instances}i | {p.width}x{p.height}x{b.camera_rays // (p.width * p.height)} | {p.depth} | {b.segments / b.camera_rays:.2f} | "
-          f"{b.kernel_ms:.2f} | {b.segments / b.kernel_ms / 1e6:.2f} | {b.camera_rays / b.kernel_ms / 1e6:.2f} | {f.kernel_ms:.2f} | {f.segments / f.kernel_ms / 1e6:.2f} |", flush=True)
+          f"{b.kernel_ms:.2f} | {b.segments / b.kernel_ms / 1e6:.2f} | {b.camera_rays / b.kernel_ms / 1e6:.2f} | {t.kernel_ms:.2f} | {t.segments / t.kernel_ms / 1e6:.2f} | {f.kernel_ms:.2f} | {f.segments / f.kernel_ms / 1e6:.2f} |", flush=True)

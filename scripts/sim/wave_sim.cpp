@@ -317,6 +317,76 @@ static Result simulate_pool(const std::vector<std::vector<std::vector<PathTrace>
     return R;
 }
 
+// ---- one path per lane, SHADE split into H (scatter at a hit), N (path ended: bank, next sample / unit, camera ray) and B (trav_begin) ----
+struct SplitCosts { double H = 1500, N = 700, B = 450, fusedS = 2800; };
+static bool g_fuse_b = false;
+static Result simulate_split(const std::vector<std::vector<std::vector<PathTrace>>> &blocks, unsigned h_hi, unsigned n_hi, unsigned b_hi, unsigned t_lo, unsigned burst,
+                             const Costs &C, const SplitCosts &SC, double *cyc_parts) {
+    Result R;
+    size_t next_block = 0, next_in_block = 0;
+    struct Unit { const std::vector<PathTrace> *paths = nullptr; size_t next = 0; };
+    auto fetch = [&](Unit &u) -> bool {
+        if (next_block >= blocks.size()) return false;
+        u.paths = &blocks[next_block][next_in_block]; u.next = 0;
+        if (++next_in_block == 64) { next_in_block = 0; next_block++; }
+        return true;
+    };
+    // lane state: 0 TRAV/LEAF (by ops), 1 wants H, 2 wants N, 3 wants B, 4 dead
+    struct L { int st = 2; Unit unit; const PathTrace *p = nullptr; size_t seg = 0, pos = 0; bool have = false; };
+    std::vector<L> lane(64);
+    auto opsof = [&](int l) -> const std::string & { return lane[l].p->seg[lane[l].seg]; };
+    unsigned long long stepsH = 0, lanesH = 0, stepsN = 0, lanesN = 0, stepsB = 0, lanesB = 0;
+    for (;;) {
+        unsigned nT = 0, nL = 0, nH = 0, nN = 0, nB = 0;
+        for (int l = 0; l < 64; l++) {
+            if (lane[l].st == 0) { if (opsof(l)[lane[l].pos] == 'N') nT++; else nL++; }
+            else if (lane[l].st == 1) nH++; else if (lane[l].st == 2) nN++; else if (lane[l].st == 3) nB++;
+        }
+        if (!(nT | nL | nH | nN | nB)) break;
+        bool starved = nT < t_lo && nL < t_lo;
+        int run = -1;                                     // 0 T 1 L 2 H 3 N 4 B
+        if (nB >= b_hi) run = 4; else if (nH >= h_hi) run = 2; else if (nN >= n_hi) run = 3;
+        else if (starved && (nB | nH | nN)) { run = nB >= nH && nB >= nN ? 4 : (nH >= nN ? 2 : 3); }
+        else run = nT >= nL ? 0 : 1;
+        auto done_query = [&](int l) {                    // traversal of the current segment finished: hit or miss?
+            const bool last = lane[l].seg + 1 >= lane[l].p->seg.size();
+            lane[l].st = last ? 2 : 1;                    // (the last query of a path is the one that ended it: miss / depth)
+        };
+        if (run == 2) {
+            stepsH++; lanesH += nH; R.cyc += SC.H; cyc_parts[0] += SC.H;
+            if (g_fuse_b) { R.cyc += SC.B; cyc_parts[0] += SC.B; }
+            for (int l = 0; l < 64; l++) if (lane[l].st == 1) { R.segments++; lane[l].seg++; lane[l].st = 3; if (g_fuse_b) { lane[l].pos = 0; lane[l].st = 0; if (opsof(l).empty()) done_query(l); } }
+        } else if (run == 3) {
+            stepsN++; lanesN += nN; R.cyc += SC.N; cyc_parts[1] += SC.N;
+            if (g_fuse_b) { R.cyc += SC.B; cyc_parts[1] += SC.B; }
+            for (int l = 0; l < 64; l++) if (lane[l].st == 2) {
+                if (lane[l].have) R.segments++;
+                if (!lane[l].have || lane[l].unit.next >= lane[l].unit.paths->size()) { if (!fetch(lane[l].unit)) { lane[l].st = 4; lane[l].have = false; continue; } }
+                lane[l].p = &(*lane[l].unit.paths)[lane[l].unit.next++]; lane[l].seg = 0; lane[l].have = true; lane[l].st = 3;
+                if (g_fuse_b) { lane[l].pos = 0; lane[l].st = 0; if (opsof(l).empty()) done_query(l); }
+            }
+        } else if (run == 4) {
+            stepsB++; lanesB += nB; R.cyc += SC.B; cyc_parts[2] += SC.B;
+            for (int l = 0; l < 64; l++) if (lane[l].st == 3) { lane[l].pos = 0; lane[l].st = 0; if (opsof(l).empty()) done_query(l); }
+        } else if (run == 0) {
+            unsigned live = nT;
+            for (unsigned u = 0; u < burst && live; u++) {
+                R.steps[0]++; R.lanes[0] += live; R.cyc += C.T;
+                live = 0;
+                for (int l = 0; l < 64; l++) if (lane[l].st == 0 && opsof(l)[lane[l].pos] == 'N') {
+                    if (++lane[l].pos >= opsof(l).size()) done_query(l); else if (opsof(l)[lane[l].pos] == 'N') live++;
+                }
+            }
+        } else {
+            R.steps[1]++; R.lanes[1] += nL; R.cyc += C.L;
+            for (int l = 0; l < 64; l++) if (lane[l].st == 0 && opsof(l)[lane[l].pos] == 'L') { if (++lane[l].pos >= opsof(l).size()) done_query(l); }
+        }
+    }
+    R.steps[2] = stepsH; R.lanes[2] = lanesH; R.steps[3] = stepsN; R.lanes[3] = lanesN;
+    cyc_parts[3] = (double)stepsB; cyc_parts[4] = (double)lanesB;
+    return R;
+}
+
 int main(int argc, char **argv) {
     uint32_t ns = 0, nt = 0, nx = 0;
     rtw_scene_generate(RTW_SCENE_C2_BOOK1_FINAL, 42, nullptr, 0, &ns, nullptr, 0, &nt, nullptr, 0, &nx);
@@ -356,6 +426,22 @@ int main(int argc, char **argv) {
             R.idleT[0] / (64.0 * R.steps[0]), R.idleT[1] / (64.0 * R.steps[0]), R.idleT[2] / (64.0 * R.steps[0]));
     };
     Policy base; report("1 path: s_hi 48 t_lo 6 (round 1)", base);
+    if (argc > 3 && !strcmp(argv[3], "split")) {
+        SplitCosts SC;
+        if (getenv("SIM_H")) SC.H = atof(getenv("SIM_H"));
+        if (getenv("SIM_N")) SC.N = atof(getenv("SIM_N"));
+        if (getenv("SIM_B")) SC.B = atof(getenv("SIM_B"));
+        g_fuse_b = getenv("SIM_FUSE_B") != nullptr;
+        for (unsigned hh : { 32u, 40u, 48u, 56u }) for (unsigned nh : { 16u, 24u, 32u, 48u }) for (unsigned bh : { 16u, 32u, 48u }) {
+            double parts[5] = { 0, 0, 0, 0, 0 };
+            Result R = simulate_split(blocks, hh, nh, bh, 6, 3, C, SC, parts);
+            auto eff = [&](int k) { return R.steps[k] ? R.lanes[k] / (64.0 * R.steps[k]) : 0.0; };
+            printf("split h_hi %2u n_hi %2u b_hi %2u: cyc/seg %7.1f | T %.3f (%4.1f%%) L %.3f (%4.1f%%) H %.3f (%4.1f%%) N %.3f (%4.1f%%) B %.3f (%4.1f%%)\n", hh, nh, bh,
+                   R.cyc / R.segments, eff(0), 100 * R.steps[0] * C.T / R.cyc, eff(1), 100 * R.steps[1] * C.L / R.cyc, eff(2), 100 * parts[0] / R.cyc,
+                   eff(3), 100 * parts[1] / R.cyc, parts[3] ? parts[4] / (64.0 * parts[3]) : 0.0, 100 * parts[2] / R.cyc);
+        }
+        return 0;
+    }
     if (argc > 3 && !strcmp(argv[3], "pool")) {
         for (unsigned K : { 96u, 128u, 192u, 256u }) for (unsigned sh : { 48u, 64u }) for (unsigned xh : { 8u, 16u, 32u }) {
             Result R = simulate_pool(blocks, K, sh, xh, 6, 3, C);

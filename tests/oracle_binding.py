@@ -11,7 +11,7 @@ import rtw_amd as R
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "librtw_oracle.so")
+ORACLE_SO = os.environ.get("RTW_ORACLE_LIB", os.path.join(ORACLE_DIR, "librtw_oracle.so"))   # override: the sanitizer build
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "librtw_ref.so")
 
 
