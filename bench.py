@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--accel", choices=["bvh", "brute"], default="bvh")
+    ap.add_argument("--config", choices=["c3", "c2", "c4", "c5"], default="c3",
+                    help="c3 = BASELINE.json's metric config (default); the others exist to profile their kernels and are NOT the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-nodes", action="store_true", help="A/B: BVH nodes in global memory (f32) instead of LDS (f16)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (INVALID as a benchmark; for smoke runs)")
@@ -108,9 +110,17 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    scene = R.Scene.generate(R.SCENE_C2, 42)
-    cam, p = R.default_view(R.SCENE_C5)          # 1920 x 1080 x 500 spp x depth 50 framing
-    cam.shutter = 0.0                            # config 3 is the static Book-1 scene
+    if args.config == "c3":
+        scene = R.Scene.generate(R.SCENE_C2, 42)
+        cam, p = R.default_view(R.SCENE_C5)          # 1920 x 1080 x 500 spp x depth 50 framing
+        cam.shutter = 0.0                            # config 3 is the static Book-1 scene
+        workload = "BASELINE configs[2]: Book-1 final random-spheres scene (485 spheres, scene seed 42)"
+    else:
+        which = {"c2": R.SCENE_C2, "c4": R.SCENE_C4, "c5": R.SCENE_C5}[args.config]
+        scene = R.Scene.generate(which, 42)
+        cam, p = R.default_view(which)
+        workload = {"c2": "BASELINE configs[1]: Book-1 final random-spheres scene", "c4": "BASELINE configs[3]: dielectric-heavy scene (183 spheres)",
+                    "c5": "BASELINE configs[4]: Book-2 motion blur + image-textured ground (485 spheres)"}[args.config] + " -- NOT the headline config"
     p.accel = R.ACCEL_BVH if args.accel == "bvh" else R.ACCEL_BRUTE
     if args.global_nodes:
         p.flags |= 4          # RTW_FLAG_GLOBAL_NODES
@@ -181,10 +191,29 @@ def main():
         k_s = kernel_ms_max / 1e3 / args.steps                      # mean kernel time per launch (slowest rank)
         flop = (nodes * F_NODE + tests * F_SPHERE + seg * F_SEGMENT) / args.steps / world   # per launch, per GPU
         achieved = flop / k_s / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")   # PMC passes of this same command (scripts/profile_bench.sh)
-        if os.path.exists(tpath) and world == 1 and not args.spp and args.accel == "bvh":
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        # Counter evidence for this same command, from the committed rocprofv3 --pmc passes (scripts/profile_bench.sh +
+        # scripts/summarise_profile.py): NOT measured in this run -- the source file is named in the line.
+        traffic, traffic_source, executed = None, None, None
+        if world == 1 and not args.spp and args.accel == "bvh" and args.config == "c3" and not args.opt:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_rocprofv3_summary.json")))
+            if cands:
+                prof = json.load(open(cands[-1]))
+                rel = os.path.relpath(cands[-1], ROOT)
+                pmc, der = prof.get("pmc", {}), prof.get("derived", {})
+                if "hbm_bytes_per_step" in der:
+                    traffic = der["hbm_bytes_per_step"]
+                    traffic_source = f"{rel}: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, render + resolve, separate --pmc passes of this command"
+                if "SQ_INSTS_VALU" in pmc and "render_kernel_avg_ms" in der:
+                    insts = pmc["SQ_INSTS_VALU"]["mean_per_dispatch"]
+                    clock = der.get("shader_clock_GHz", 2.4)
+                    lane_peak = der["render_kernel_avg_ms"] * 1e-3 * clock * 1e9 * 1024 * 32      # 1024 SIMDs x 32 lanes per clock
+                    executed = {"source": f"{rel} (rocprofv3 --pmc passes of this command; kernel {der['render_kernel_avg_ms']:.2f} ms under the profiler)",
+                                "SQ_INSTS_VALU": insts, "lane_slots": insts * 64,
+                                "lane_utilisation": round(der.get("valu_lane_utilisation", 0.0), 4),
+                                "issue_fraction_of_lane_peak": round(insts * 64 / lane_peak, 4),
+                                "live_lane_fraction_of_lane_peak": round(insts * 64 * der.get("valu_lane_utilisation", 0.0) / lane_peak, 4),
+                                "valu_issues_per_cycle_per_simd": round(der.get("valu_issues_per_cycle_per_simd", 0.0), 4)}
         out = {
             "metric": "Msamples/s (rays x bounces) at 1920x1080x500spp",
             "value": round(seg / elapsed / 1e6, 3), "unit": "Msamples/s",
@@ -192,15 +221,16 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: Book-1 final random-spheres scene (485 spheres, scene seed 42), "
+            "config": {"workload": workload + ", "
                                    f"{W}x{H}, {p.samples} spp (render_row sampler), depth {p.depth}, gradient sky, render seed 1; "
                                    "rows in interleaved 8-row blocks per GPU + " +
                                    ("rtw_mgpu (one process, strided peer copies into GPU 0's frame)" if single_process_multi else "one RCCL gather"),
                        "accel": args.accel, "camera_msamples_per_s": round(rays / elapsed / 1e6, 3),
                        "segments_per_camera_ray": round(seg / max(rays, 1), 4)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_TFLOPS, 5), "traffic": traffic,
-                         "kernel": "rtw::render_%s<moving=false> + rtw::resolve_kernel (timed together: HIP events around both)" % args.accel,
+                         "frac": round(achieved / PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                         "executed_valu": executed,
+                         "kernel": "rtw::render_%s + rtw::resolve_kernel (timed together: HIP events around both)" % args.accel,
                          "kernel_ms": round(k_s * 1e3, 3),
                          "algorithmic_flop_per_launch": flop,
                          "scheduler_census_rank0": {n: {"wave_steps": steps3[k] // args.steps,
@@ -209,8 +239,11 @@ def main():
                          "units_per_launch": {"segments": seg / args.steps / world, "node_visits": nodes / args.steps / world,
                                               "sphere_tests": tests / args.steps / world},
                          "hbm": {"achieved": round((H * W * 12 + rays / args.steps * 24) / world / k_s / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
-                                 "note": "algorithmic bytes: 12 B per camera ray written to the per-sample bank + read back "
-                                         "by the in-order resolve, + 12 B/pixel framebuffer; the path is not HBM-bound"}},
+                                 "framebuffer_bytes": H * W * 12 / world,
+                                 "sample_bank_bytes": rays / args.steps * 24 / world,
+                                 "note": "algorithmic bytes per launch: framebuffer 12 B/pixel (what SURVEY 8d counts) + the builder's own per-sample "
+                                         "bank, 12 B per camera ray written by the render kernel and read back by the in-order resolve; "
+                                         "the path is not HBM-bound"}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(R, scene, cam, p)
