@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-nodes", action="store_true", help="A/B: BVH nodes in global memory (f32) instead of LDS (f16)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (INVALID as a benchmark; for smoke runs)")
+    ap.add_argument("--chunk-sums", action="store_true", help="RTW_FLAG_CHUNK_SUMS: bank one partial sum per 4 samples (A/B; not the default association)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="rtw_ctx_set_option, e.g. --opt 4=5 (RTW_OPT_BLOCKS_PER_CU = 5) or --opt 6=1 (one path per lane); A/B runs")
     ap.add_argument("--devices", default="", help="single-process rtw_mgpu over these HIP ordinals, e.g. 0,0,0 = three contexts on one GPU "
@@ -124,6 +125,8 @@ def main():
     p.accel = R.ACCEL_BVH if args.accel == "bvh" else R.ACCEL_BRUTE
     if args.global_nodes:
         p.flags |= 4          # RTW_FLAG_GLOBAL_NODES
+    if args.chunk_sums:
+        p.flags |= 16         # RTW_FLAG_CHUNK_SUMS
     if args.spp:
         p.samples = args.spp
     H, W = p.height, p.width
@@ -194,7 +197,7 @@ def main():
         # Counter evidence for this same command, from the committed rocprofv3 --pmc passes (scripts/profile_bench.sh +
         # scripts/summarise_profile.py): NOT measured in this run -- the source file is named in the line.
         traffic, traffic_source, executed = None, None, None
-        if world == 1 and not args.spp and args.accel == "bvh" and args.config == "c3" and not args.opt:
+        if world == 1 and not args.spp and args.accel == "bvh" and args.config == "c3" and not args.opt and not args.chunk_sums:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_rocprofv3_summary.json")))
             if cands:

@@ -200,13 +200,13 @@ typedef struct RtwParams {
                                         unit(reflect(unit(d), n)); a near-zero (1e-8) result becomes the normal.
                                         RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE is what Viewport::RenderGPU of the C++
                                         tree asks for. */
-#define RTW_FLAG_CHUNK_SUMS     16u  /* device only: a lane adds the samples of its work unit (RTW_OPT_CHUNK_LEN consecutive samples
-                                        of one pixel) in registers and banks ONE partial sum per unit; the resolve pass adds the
-                                        partial sums in chunk order.  Deterministic and independent of the GPU split like the default,
-                                        but the f32 summation is associated per chunk, ((s0+s1+s2+s3) + (s4+..)) + .., instead of the
-                                        reference's left-to-right order (viewport.rs:299): the image differs by rounding only
-                                        (<= 1e-6 relative, inside BASELINE.json's 1e-3), and the bank shrinks by chunk_len
-                                        (12.4 GB -> 3.1 GB at 1920x1080x500). */
+#define RTW_FLAG_CHUNK_SUMS     16u  /* keep ONE partial sum per pixel and RTW_SUM_CHUNK consecutive samples in the device's sample bank instead
+                                        of every sample: the samples of a chunk are added left to right, the chunks' sums in chunk order,
+                                        ((s0+s1+s2+s3) + (s4+..)) + ..  Deterministic and independent of the GPU split like the default, but
+                                        not the reference's left-to-right association (viewport.rs:299): the image differs by f32 rounding
+                                        only (<= 2e-6 relative, far inside BASELINE.json's 1e-3).  The bank shrinks 4x (12.4 GB -> 3.1 GB at
+                                        1920x1080x500).  The oracle implements the same association under the same flag. */
+#define RTW_SUM_CHUNK            4u
 
 typedef struct RtwStats {
     uint64_t camera_rays;    /* (pixel, sample) primary rays traced                   */

@@ -706,7 +706,7 @@ static void render_pixel(const RtwCamera *cam, const RtwScene *sc, const RtwPara
     float inv_g = 1.0f / p->gamma;                                  /* viewport.rs:232,439 */
     uint32_t s_root, n = sampler_count(p->sampler, p->samples, &s_root);
     uint32_t pixel = j * p->width + i;
-    v3 color = v3_make(0, 0, 0);
+    v3 color = v3_make(0, 0, 0), part = v3_make(0, 0, 0);
     ctx_t c; memset(&c, 0, sizeof c); c.sc = sc; c.p = p; c.cn = cn;
 
     if (p->sampler == RTW_SAMPLER_NO_RAND) {                        /* viewport.rs:498-508 */
@@ -748,6 +748,13 @@ static void render_pixel(const RtwCamera *cam, const RtwScene *sc, const RtwPara
             r.dir = v3_add(v3_add(p00, v3_scale(du, jx)), v3_scale(dv, jy));
             r.time = 0.0f;
         }
+        if (p->flags & RTW_FLAG_CHUNK_SUMS) {
+            /* device-mode restated (rtw.h): the samples of a chunk of RTW_SUM_CHUNK are added left to right into a partial sum,
+             * the partial sums are added in chunk order */
+            v3 L = ray_color(&c, r);
+            part = (s % RTW_SUM_CHUNK) == 0 ? L : v3_add(part, L);
+            if ((s % RTW_SUM_CHUNK) == RTW_SUM_CHUNK - 1 || s + 1 == n) color = v3_add(color, part);
+        } else
         color = v3_add(color, ray_color(&c, r));                    /* :299 color += */
     }
     *camera_rays += n;

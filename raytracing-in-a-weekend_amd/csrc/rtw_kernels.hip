@@ -40,6 +40,8 @@ namespace rtw {
 // SPEC != 0 is the specialisation for the common configuration -- ray_color_gradient, render_row sampler, depth >= 1
 // (every BASELINE config): the integrator/sampler switches fold away at compile time.  SPEC == 1 additionally knows
 // that no sphere carries an image texture (no atan2f/acosf code at all); SPEC == 2 keeps the texture lookup (C5).
+// SPEC == 3 is SPEC == 1 with RTW_FLAG_CHUNK_SUMS (one partial sum per work unit in the bank); the generic build honours the flag at run
+// time; a runtime test of it in the SPEC == 1 / 2 builds cost the bench frame 0.8 % (gpurun_out/r02_ab_chunk.log), hence a build of its own.
 // SPEC == 0 reads everything from the (wave-uniform) kernel arguments.
 template <int SPEC> __device__ __forceinline__ uint32_t integ(const KArgs &A) { return SPEC ? (uint32_t)RTW_INTEGRATOR_GRADIENT : A.integrator; }
 template <int SPEC> __device__ __forceinline__ uint32_t samp(const KArgs &A) { return SPEC ? (uint32_t)RTW_SAMPLER_ROW : A.sampler; }
@@ -220,7 +222,7 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, v3 ud, int b
     const v3 point = pt.o + pt.d * best_t;                   // r.at(x)
     const v3 normal = unit(point - c);                       // sphere.rs:127
     const DevMat mat = sc.mat[best];
-    const v3 cm = SPEC == 1 ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
+    const v3 cm = (SPEC == 1 || SPEC == 3) ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
     return shade_surface<SPEC>(A, pt, ud, point, normal, cm, mat_params(mat), ld3(mat.emitted));
 }
 
@@ -247,9 +249,20 @@ __device__ __forceinline__ bool shade_geom(const KArgs &A, Path &pt, int best, f
 
 // A path ended: bank its radiance in the sample buffer (the resolve kernel adds the samples of a pixel
 // in sample order, viewport.rs:299).  Returns true when the unit is done.
+template <int SPEC>
 __device__ __forceinline__ bool finish_path(const KArgs &A, Pixel &px, Path &pt) {
     if (pt.poison) { const float qn = __builtin_nanf(""); pt.L = mk(qn, qn, qn); }
-    *reinterpret_cast<float3 *>(A.samples + 3 * (size_t)px.slot) = make_float3(pt.L.x, pt.L.y, pt.L.z);   // one 12-byte store
+    float3 *dst = reinterpret_cast<float3 *>(A.samples + 3 * (size_t)px.slot);
+    if (SPEC == 3 || (SPEC == 0 && (A.flags & RTW_FLAG_CHUNK_SUMS))) {        // one slot per unit, the unit's samples added into it in sample order
+        if (px.s & (RTW_SUM_CHUNK - 1u)) {      // (chunk_len == RTW_SUM_CHUNK in this mode, units start on multiples of it)
+            const float3 acc = *dst;
+            pt.L = mk(acc.x, acc.y, acc.z) + pt.L;
+        }
+        *dst = make_float3(pt.L.x, pt.L.y, pt.L.z);
+        px.s++;
+        return px.s >= px.s_end;
+    }
+    *dst = make_float3(pt.L.x, pt.L.y, pt.L.z);   // one 12-byte store
     px.slot += 64u; px.s++;
     return px.s >= px.s_end;
 }
@@ -268,9 +281,10 @@ __global__ __launch_bounds__(RTW_BLOCK) void resolve_kernel(const KArgs A) {
             v3 acc = mk(0, 0, 0);
             uint32_t s = 0;
             for (uint32_t c = 0; c < A.n_chunks; c++) {
-                const float *src = A.samples + 3 * ((size_t)(tile * A.n_chunks + c) * 64u * A.chunk_len + p);
+                const float *src = A.samples + 3 * ((size_t)(tile * A.n_chunks + c) * 64u * A.bank_len + p);
                 const uint32_t cnt = s + A.chunk_len < A.n_samples ? A.chunk_len : A.n_samples - s;
-                for (uint32_t q = 0; q < cnt; q++) acc = acc + ld3(src + 3 * 64u * q);     // viewport.rs:299
+                // (RTW_FLAG_CHUNK_SUMS: bank_len == 1, the slot already holds the chunk's sum)
+                for (uint32_t q = 0; q < (A.bank_len == 1u ? 1u : cnt); q++) acc = acc + ld3(src + 3 * 64u * q);     // viewport.rs:299
                 s += cnt;
             }
             v3 col = acc / (float)A.n_samples;                   // viewport.rs:301
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 4 : 1) void render_brute(const KA
                 finished = GEOM ? shade_geom<MOVING>(A, pt, best, best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, best, best_t);
             }
             if (finished) {
-                if (finish_path(A, px, pt)) have = false;
+                if (finish_path<SPEC>(A, px, pt)) have = false;
                 else newpath = true;
             }
         }
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
                     const bool done = GEOM ? shade_geom<MOVING>(A, pt, tr.best, tr.best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t);
                     if (done) fl |= F_DONE;
                 }
-                if (fl & F_DONE) { fl &= ~F_DONE; if (finish_path(A, px, pt)) fl &= ~F_HAVE; else fl |= F_NEWPATH; }
+                if (fl & F_DONE) { fl &= ~F_DONE; if (finish_path<SPEC>(A, px, pt)) fl &= ~F_HAVE; else fl |= F_NEWPATH; }
                 need_unit = (fl & F_HAVE) == 0u;
             }
             // b. next work unit.  Executed by EVERY lane of the wave (not only the ones in SHADE): the wave's
@@ -785,6 +799,7 @@ static kernel_fn pick_kernel_geom(bool moving, uint32_t accel, bool lds_nodes) {
 static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes) {
     if (a.geom.n_quads || a.geom.n_inst) return pick_kernel_geom(moving, accel, lds_nodes);
     if (!is_common_config(a)) return pick_kernel_spec<0>(moving, accel, lds_nodes);
+    if (a.flags & RTW_FLAG_CHUNK_SUMS) return a.has_textures ? pick_kernel_spec<0>(moving, accel, lds_nodes) : pick_kernel_spec<3>(moving, accel, lds_nodes);
     return a.has_textures ? pick_kernel_spec<2>(moving, accel, lds_nodes) : pick_kernel_spec<1>(moving, accel, lds_nodes);
 }
 

@@ -336,7 +336,6 @@ static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, 
     if (p->integrator > RTW_INTEGRATOR_RUST2 || p->sampler > RTW_SAMPLER_NO_RAND || p->accel > RTW_ACCEL_BVH) return RTW_E_INVALID;
     if (p->part_count > 1 && (p->row_block == 0 || p->part_index >= p->part_count)) return RTW_E_INVALID;
     if ((uint64_t)p->width * p->height >= (1ull << 32)) return RTW_E_INVALID;
-    if (p->flags & RTW_FLAG_CHUNK_SUMS) return RTW_E_UNSUPPORTED;    // TODO(round 2): declared in rtw.h, kernel support pending
     c->pend.t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(c->device));
 
@@ -391,7 +390,7 @@ static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, 
     // Every sample's radiance is banked in HBM and added in order by resolve_kernel: 12 B per camera ray
     // (12.4 GB for 1920x1080x500) -- the image is rendered in bands of tile rows when that exceeds the budget.
     // RTW_FLAG_CHUNK_SUMS banks one partial sum per unit instead (bank_len = 1 slot per unit and pixel).
-    uint32_t chunk_len = c->opt_chunk_len;
+    uint32_t chunk_len = (p->flags & RTW_FLAG_CHUNK_SUMS) ? RTW_SUM_CHUNK : c->opt_chunk_len;   // (the summation chunk is part of the image's definition)
     if (chunk_len > a.n_samples) chunk_len = a.n_samples;
     a.chunk_len = chunk_len;
     a.n_chunks = (a.n_samples + chunk_len - 1) / chunk_len;

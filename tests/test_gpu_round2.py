@@ -261,3 +261,33 @@ def test_c3_one_block_against_the_oracle(gpu):
     img, st = gpu.render(cam, p)
     assert st.rows == 8 and st.camera_rays == 8 * 1920 * 500 and st.segments == st_ref.segments
     assert np.array_equal(img, ref)
+
+
+# ---- RTW_FLAG_CHUNK_SUMS: one partial sum per (pixel, 4 samples) in the bank instead of every sample ---------------------------------
+@pytest.mark.parametrize("samples", [1, 3, 4, 10, 37])
+def test_chunk_sums_mode(gpu, samples):
+    """The chunked association ((s0+s1+s2+s3) + (s4+..)) + .. is implemented by the oracle under the same flag: bit-identical;
+    against the reference's left-to-right order it differs by f32 rounding only; the image stays independent of the row split
+    and of the work-unit option."""
+    scene, cam, p = small_view(R.SCENE_C2, 96, 54, samples)
+    p.gamma = 1.0
+    ordered, _ = O.render(cam, scene, p, threads=16)
+    p.flags = R.FLAG_CHUNK_SUMS
+    ref, st_ref = O.render(cam, scene, p, threads=16)
+    with R.Renderer(0) as r:
+        r.set_scene(scene)
+        for accel in (R.ACCEL_BRUTE, R.ACCEL_BVH):
+            p.accel = accel
+            img, st = r.render(cam, p)
+            assert st.segments == st_ref.segments and np.array_equal(img, ref), accel
+        r.set_option(R.OPT_CHUNK_LEN, 7)                       # ignored in this mode: the summation chunk defines the image
+        img2, _ = r.render(cam, p)
+        assert np.array_equal(img2, ref)
+        p.row_block, p.part_index, p.part_count = 8, 1, 3
+        part, _ = r.render(cam, p)
+        rows = [j for j in range(54) if (j // 8) % 3 == 1]
+        assert np.array_equal(part, ref[rows])
+    rel = np.abs(ref - ordered) / np.maximum(np.abs(ordered), 1e-6)
+    assert rel.max() < 2e-6 * max(1, samples // 4), rel.max()
+    if samples <= 4:
+        assert np.array_equal(ref, ordered)                    # a single chunk IS the left-to-right sum

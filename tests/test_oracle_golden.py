@@ -435,3 +435,21 @@ def test_cpp_diffuse_known_answers():
         b, _ = O.trace_ray((0, 0, 0), (0.05, 0.02, -1.0), 0.0, scene, p)
         dirs.append(np.array(b[0].next_dir, np.float64))
     assert np.abs(dirs[0] - dirs[1]).max() < 3e-7 and abs(np.linalg.norm(dirs[1]) - 1.0) < 3e-7
+
+
+def test_chunk_sums_flag_on_the_oracle():
+    """RTW_FLAG_CHUNK_SUMS (rtw.h) on the CPU side: <= 4 samples is the plain left-to-right sum; more samples differ from it by
+    rounding only, and threads / partitions still do not matter."""
+    scene, cam, p = small_view(R.SCENE_C2, 48, 27, 4)
+    p.gamma = 1.0
+    a, _ = O.render(cam, scene, p)
+    p.flags = R.FLAG_CHUNK_SUMS
+    b, _ = O.render(cam, scene, p)
+    assert np.array_equal(a, b)
+    p.samples, p.flags = 23, 0
+    a, _ = O.render(cam, scene, p, threads=1)
+    p.flags = R.FLAG_CHUNK_SUMS
+    b, _ = O.render(cam, scene, p, threads=1)
+    c, _ = O.render(cam, scene, p, threads=8)
+    assert np.array_equal(b, c) and not np.array_equal(a, b)
+    assert (np.abs(a - b) / np.maximum(np.abs(a), 1e-6)).max() < 1e-5
