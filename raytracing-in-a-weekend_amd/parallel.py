@@ -29,27 +29,31 @@ def max_rows(height: int, world: int, row_block: int = ROW_BLOCK) -> int:
     return max(len(rows_of(height, r, world, row_block)) for r in range(max(1, world)))
 
 
+_cache = {}      # (height, width, world, row_block, device, dtype) -> (row index tensors per rank, receive buffers, frame): built once, reused every frame
+
+
 def gather_frame(local: torch.Tensor, height: int, width: int, rank: int, world: int,
                  row_block: int = ROW_BLOCK, group=None) -> Optional[torch.Tensor]:
     """`local` is this rank's padded [max_rows][W][3] buffer (first rows_r rows valid).  Returns the
-    [H][W][3] frame on rank 0, None elsewhere."""
+    [H][W][3] frame on rank 0, None elsewhere.  (The returned frame is reused by the next call.)"""
     if world <= 1:
         return local[:height]
     device = local.device
     if local.is_cuda and dist.get_backend(group) == "gloo":
         local = local.cpu()          # rehearsal of the N > 1 path without RCCL (tests): gloo gathers host tensors
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    bufs = idx = frame = None
+    if rank == 0:
+        key = (height, width, world, row_block, str(device), str(local.device), local.dtype)
+        if key not in _cache:        # per-frame host work on rank 0 is then ONE gather + `world` index_copy_ launches
+            idx = [torch.as_tensor(rows_of(height, r, world, row_block), dtype=torch.long, device=device) for r in range(world)]
+            _cache[key] = (idx, [torch.empty_like(local) for _ in range(world)], torch.empty((height, width, 3), dtype=local.dtype, device=device))
+        idx, bufs, frame = _cache[key]
     dist.gather(local, gather_list=bufs, dst=0, group=group)
     if rank != 0:
         return None
-    if bufs[0].device != device:
-        bufs = [b.to(device) for b in bufs]
-        local = local.to(device)
-    frame = torch.empty((height, width, 3), dtype=local.dtype, device=local.device)
     for r in range(world):
-        rows = rows_of(height, r, world, row_block)
-        idx = torch.as_tensor(rows, dtype=torch.long, device=local.device)
-        frame.index_copy_(0, idx, bufs[r][: len(rows)])
+        src = bufs[r] if bufs[r].device == device else bufs[r].to(device)
+        frame.index_copy_(0, idx[r], src[: idx[r].numel()])
     return frame
 
 
