@@ -57,6 +57,7 @@ extern "C" {
                             out_rgb: *mut c_void, st: *mut RtwStats) -> i32;
     fn rtw_strerror(status: i32) -> *const std::os::raw::c_char;
     fn rtw_part_rows(height: u32, row_block: u32, part_index: u32, part_count: u32) -> u32;
+    fn rtw_ctx_set_option(ctx: *mut RtwCtx, key: u32, value: f64) -> i32;
     fn rtw_mgpu_create(devices: *const i32, n: u32, out: *mut *mut RtwMgpu) -> i32;
     fn rtw_mgpu_destroy(m: *mut RtwMgpu);
     fn rtw_mgpu_set_scene(m: *mut RtwMgpu, scene: *const RtwScene, t_begin: f32, t_end: f32) -> i32;
@@ -104,6 +105,9 @@ impl Renderer {
             n_inst_spheres: inst_spheres.len() as u32, n_inst_quads: inst_quads.len() as u32 };
         check(unsafe { rtw_ctx_set_scene(self.ctx, &sc, t_begin, t_end) })
     }
+    /// Tuning knobs (`RTW_OPT_*` of rtw.h: 1 chunk length, 2 sample bank GiB, 3 LDS geometry, 4 workgroups per CU, 5 list-walk
+    /// threshold); none of them changes the image.
+    pub fn set_option(&mut self, key: u32, value: f64) -> Result<(), RtwError> { check(unsafe { rtw_ctx_set_option(self.ctx, key, value) }) }
     /// -> `Img`-shaped rows ([height][width] of Rgb<f32>), gamma-corrected, unclamped (viewport.rs:301).
     pub fn render(&mut self, cam: &RtwCamera, p: &RtwParams) -> Result<(Vec<Vec<[f32; 3]>>, RtwStats), RtwError> {
         // a row partition (RtwParams.part_count > 1) returns only the rows it owns, compactly

@@ -5,6 +5,8 @@
 //   render_scene --scene metal --out metal_test.png
 //   render_scene --scene presentation --out Presentation.png      (presentation_image, Rust/src/main.rs:89-419)
 //   render_scene --json scene.json --width 400 --height 225 --spp 100 --depth 10 --out scene.png
+//   render_scene --scene book1 --devices 0,1,2,3,4,5,6,7 --out book1.png   (one frame over eight GPUs: rtw_render_multi_gpu, the
+//                                                                            fork / ordered join of Rust/src/viewport.rs:236-244)
 #include "rtw.h"
 
 #include <cstdio>
@@ -19,6 +21,7 @@ int main(int argc, char **argv) {
     std::string scene_name = "metal", json_path, out = "out.png", dump_json;
     uint32_t width = 0, height = 0, spp = 0, depth = 0, accel = RTW_ACCEL_BVH;
     uint64_t seed = 1;
+    std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -32,6 +35,7 @@ int main(int argc, char **argv) {
         else if (a == "--depth") depth = (uint32_t)std::atoi(next());
         else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--accel") accel = std::string(next()) == "brute" ? RTW_ACCEL_BRUTE : RTW_ACCEL_BVH;
+        else if (a == "--devices") { for (const char *q = next(); *q;) { devices.push_back(std::atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     uint32_t which = scene_name == "c1" ? RTW_SCENE_C1_THREE_SPHERES : scene_name == "book1" ? RTW_SCENE_C2_BOOK1_FINAL
@@ -101,7 +105,16 @@ int main(int argc, char **argv) {
 
     std::vector<float> img((size_t)3 * p.width * p.height);
     RtwStats st;
-    if ((rc = rtw_render(&cam, &scene, &p, img.data(), &st))) return die("rtw_render", rc);
+    if (!devices.empty()) {                         // one frame over several GPUs, straight into this host buffer
+        std::vector<RtwStats> per(devices.size());
+        if ((rc = rtw_render_multi_gpu(devices.data(), (uint32_t)devices.size(), &cam, &scene, &p, img.data(), per.data()))) return die("rtw_render_multi_gpu", rc);
+        st = per[0];
+        for (size_t k = 1; k < per.size(); k++) {
+            st.camera_rays += per[k].camera_rays; st.segments += per[k].segments; st.nan_pixels += per[k].nan_pixels;
+            if (per[k].kernel_ms > st.kernel_ms) st.kernel_ms = per[k].kernel_ms;
+        }
+        std::printf("%zu devices: ", devices.size());
+    } else if ((rc = rtw_render(&cam, &scene, &p, img.data(), &st))) return die("rtw_render", rc);
     std::printf("%u spheres + %u quads + %u instances, %ux%u, %llu camera rays, %llu segments, %.3f ms on the GPU (%.2f Gsegments/s), %u NaN pixels\n",
                 ns, scene.n_quads, scene.n_instances, p.width, p.height, (unsigned long long)st.camera_rays, (unsigned long long)st.segments, st.kernel_ms,
                 st.segments / (st.kernel_ms * 1e6), st.nan_pixels);

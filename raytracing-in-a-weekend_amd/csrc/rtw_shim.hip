@@ -392,6 +392,10 @@ static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, 
     // RTW_FLAG_CHUNK_SUMS banks one partial sum per unit instead (bank_len = 1 slot per unit and pixel).
     uint32_t chunk_len = (p->flags & RTW_FLAG_CHUNK_SUMS) ? RTW_SUM_CHUNK : c->opt_chunk_len;   // (the summation chunk is part of the image's definition)
     if (chunk_len > a.n_samples) chunk_len = a.n_samples;
+    // a frame so small that one workgroup per CU is enough (below): halve the unit, the tail of the launch is one unit deep
+    // (C1: 0.276 -> 0.261 ms, profiles/r02_small_frame.log)
+    if (!(p->flags & RTW_FLAG_CHUNK_SUMS) && chunk_len >= 4 &&
+        (uint64_t)a.tiles_x * ((n_rows + 7) / 8) * ((a.n_samples + chunk_len - 1) / chunk_len) * 64ull < (uint64_t)c->n_cu * RTW_BLOCK * 16ull) chunk_len /= 2;
     a.chunk_len = chunk_len;
     a.n_chunks = (a.n_samples + chunk_len - 1) / chunk_len;
     a.bank_len = (p->flags & RTW_FLAG_CHUNK_SUMS) ? 1u : chunk_len;
