@@ -80,6 +80,80 @@ static int closest(const Scene &S, V o, V d, float &best_t, std::string &ops) {
     return best;
 }
 
+
+// ---- uniform grid over the tree spheres (design study): cells hold sphere lists; a query = DDA steps ('N') + exact tests ('L') ----
+struct Grid {
+    float lo[3], inv_cell[3], cell[3]; int n[3];
+    std::vector<std::vector<uint32_t>> cells; std::vector<float> ymax;
+};
+static Grid g_grid; static bool g_use_grid = false;
+static void build_grid(const Scene &S, float target_per_cell) {
+    Grid &G = g_grid;
+    float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+    std::vector<char> big(S.sp.size(), 0); for (uint32_t i : S.bvh.big) big[i] = 1;
+    size_t cnt = 0;
+    for (size_t i = 0; i < S.sp.size(); i++) if (!big[i]) { cnt++; for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], S.sp[i].center[k] - S.sp[i].radius); hi[k] = std::max(hi[k], S.sp[i].center[k] + S.sp[i].radius); } }
+    // cells ~ cube root rule on the two large axes; y gets 1 cell when the scene is flat
+    float ext[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] };
+    float vol = ext[0] * ext[1] * ext[2];
+    float cs = std::cbrt(vol * target_per_cell / cnt);
+    if (getenv("SIM_CELL")) cs = (float)atof(getenv("SIM_CELL"));          // cell edge given directly (all axes)
+    for (int k = 0; k < 3; k++) { G.n[k] = std::max(1, (int)std::floor(ext[k] / cs)); G.cell[k] = ext[k] / G.n[k]; G.inv_cell[k] = 1.0f / G.cell[k]; G.lo[k] = lo[k]; }
+    G.cells.assign((size_t)G.n[0] * G.n[1] * G.n[2], {});
+    for (size_t i = 0; i < S.sp.size(); i++) if (!big[i]) {
+        int a[3], b[3];
+        for (int k = 0; k < 3; k++) {
+            a[k] = std::max(0, std::min(G.n[k] - 1, (int)std::floor((S.sp[i].center[k] - S.sp[i].radius - lo[k]) * G.inv_cell[k])));
+            b[k] = std::max(0, std::min(G.n[k] - 1, (int)std::floor((S.sp[i].center[k] + S.sp[i].radius - lo[k]) * G.inv_cell[k])));
+        }
+        for (int x = a[0]; x <= b[0]; x++) for (int y = a[1]; y <= b[1]; y++) for (int z = a[2]; z <= b[2]; z++) G.cells[((size_t)x * G.n[1] + y) * G.n[2] + z].push_back((uint32_t)i);
+    }
+    size_t refs = 0, nonempty = 0; for (auto &c : G.cells) { refs += c.size(); nonempty += !c.empty(); }
+    printf("grid %d x %d x %d, cell %.2f x %.2f x %.2f, %zu sphere refs (%.2f per sphere), %zu / %zu cells non-empty\n", G.n[0], G.n[1], G.n[2], G.cell[0], G.cell[1], G.cell[2],
+           refs, (double)refs / cnt, nonempty, G.cells.size());
+}
+static int closest_grid(const Scene &S, V o, V d, float &best_t, std::string &ops) {
+    const Grid &G = g_grid;
+    const float mint = 0.001f;
+    int best = -1; best_t = 1e5f;
+    for (uint32_t i : S.bvh.big) { float t; if (hit_sphere(S.sp[i], o, d, mint, best_t, t) && t < best_t) { best_t = t; best = (int)i; } }
+    // clip the ray to the grid box
+    float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    float t0 = mint, t1 = best_t;
+    for (int k = 0; k < 3; k++) {
+        float hi = G.lo[k] + G.cell[k] * G.n[k];
+        if (dd[k] == 0) { if (oo[k] < G.lo[k] || oo[k] > hi) return best; continue; }
+        float a = (G.lo[k] - oo[k]) / dd[k], b = (hi - oo[k]) / dd[k]; if (a > b) std::swap(a, b);
+        t0 = std::max(t0, a); t1 = std::min(t1, b);
+    }
+    ops.push_back('N');                       // the set-up step (clip + first cell) costs about one step
+    if (t0 > t1) return best;
+    int c[3], step[3]; float tn[3], dt[3];
+    for (int k = 0; k < 3; k++) {
+        float p = oo[k] + dd[k] * t0;
+        c[k] = std::max(0, std::min(G.n[k] - 1, (int)std::floor((p - G.lo[k]) * G.inv_cell[k])));
+        step[k] = dd[k] > 0 ? 1 : -1;
+        if (dd[k] == 0) { tn[k] = 1e30f; dt[k] = 1e30f; }
+        else { float edge = G.lo[k] + (c[k] + (dd[k] > 0 ? 1 : 0)) * G.cell[k]; tn[k] = (edge - oo[k]) / dd[k]; dt[k] = G.cell[k] / std::fabs(dd[k]); }
+    }
+    uint32_t last = 0xFFFFFFFFu;
+    for (;;) {
+        const auto &cell = G.cells[((size_t)c[0] * G.n[1] + c[1]) * G.n[2] + c[2]];
+        float t_exit = std::min(tn[0], std::min(tn[1], tn[2]));
+        for (uint32_t s : cell) {
+            if (s == last) continue; last = s;
+            ops.push_back('L'); float t;
+            if (hit_sphere(S.sp[s], o, d, mint, best_t, t) && t < best_t) { best_t = t; best = (int)s; }
+        }
+        if (best_t <= t_exit || t_exit >= t1) break;
+        int k = tn[0] <= tn[1] ? (tn[0] <= tn[2] ? 0 : 2) : (tn[1] <= tn[2] ? 1 : 2);
+        c[k] += step[k]; tn[k] += dt[k];
+        if (c[k] < 0 || c[k] >= G.n[k]) break;
+        ops.push_back('N');
+    }
+    return best;
+}
+
 struct PathTrace { std::vector<std::string> seg; };     // one string of ops per closest-hit query of the path
 
 static PathTrace trace_path(const Scene &S, const RtwCamera &cam, uint32_t i, uint32_t j, uint32_t depth) {
@@ -91,7 +165,7 @@ static PathTrace trace_path(const Scene &S, const RtwCamera &cam, uint32_t i, ui
     V d = V{ cam.pixel00[0], cam.pixel00[1], cam.pixel00[2] } + V{ cam.delta_u[0], cam.delta_u[1], cam.delta_u[2] } * jx + V{ cam.delta_v[0], cam.delta_v[1], cam.delta_v[2] } * jy;
     for (uint32_t k = 0; k < depth; k++) {
         std::string ops; float t;
-        int best = closest(S, o, d, t, ops);
+        int best = g_use_grid ? closest_grid(S, o, d, t, ops) : closest(S, o, d, t, ops);
         pt.seg.push_back(ops);
         if (best < 0) break;
         const RtwSphere &s = S.sp[best];
@@ -393,6 +467,15 @@ int main(int argc, char **argv) {
     Scene S; S.sp.resize(ns);
     rtw_scene_generate(RTW_SCENE_C2_BOOK1_FINAL, 42, S.sp.data(), ns, &ns, nullptr, 0, &nt, nullptr, 0, &nx);
     build_bvh(S.sp.data(), ns, 0, 0, S.bvh);
+    if (getenv("SIM_GRID")) { g_use_grid = true; build_grid(S, (float)atof(getenv("SIM_GRID"))); }
+    if (getenv("SIM_SCENE")) {                 // other generator scenes: 4 = dielectric-heavy
+        uint32_t which = (uint32_t)atoi(getenv("SIM_SCENE"));
+        rtw_scene_generate(which, 42, nullptr, 0, &ns, nullptr, 0, &nt, nullptr, 0, &nx);
+        S.sp.resize(ns); std::vector<RtwTexture> tx(nt ? nt : 1); std::vector<float> tl(3 * (nx ? nx : 1));
+        rtw_scene_generate(which, 42, S.sp.data(), ns, &ns, tx.data(), nt, &nt, tl.data(), nx, &nx);
+        build_bvh(S.sp.data(), ns, 0, 0, S.bvh);
+        if (g_use_grid) build_grid(S, (float)atof(getenv("SIM_GRID")));
+    }
     RtwCamera cam; RtwParams p;
     rtw_scene_default_view(RTW_SCENE_C5_MOTION_CHECKER, &cam, &p);
     const uint32_t chunk = 4, n_tiles = argc > 1 ? atoi(argv[1]) : 40, chunks_per_tile = argc > 2 ? atoi(argv[2]) : 6;
@@ -415,6 +498,8 @@ int main(int argc, char **argv) {
            (double)nN / nseg, (double)nL / nseg, (double)nseg / (blocks.size() * 64.0 * chunk));
     Costs C;
     if (getenv("SIM_X")) C.X = atof(getenv("SIM_X"));
+    if (getenv("SIM_T")) C.T = atof(getenv("SIM_T"));
+    if (getenv("SIM_L")) C.L = atof(getenv("SIM_L"));
     if (getenv("SIM_S")) C.S = atof(getenv("SIM_S"));
     auto report = [&](const char *name, const Policy &P) {
         Result R = simulate(blocks, P, C);
