@@ -1,0 +1,127 @@
+"""Property tests (hypothesis) of the product's HOST code -- the parts that take untrusted sizes and bytes: the JSON scene
+reader, the BVH builder, the row partition, the constructors.  CPU only; the same tests run under ASan + UBSan through
+scripts/run_cpu_tests_asan.sh."""
+import ctypes as C
+import json
+import math
+
+import numpy as np
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import rtw_amd as R
+
+SET = dict(deadline=None, suppress_health_check=[HealthCheck.too_slow])
+finite = st.floats(min_value=-1e6, max_value=1e6, allow_nan=False, width=32)
+weird = st.sampled_from([0.0, -0.0, 1e-30, -1e-30, 1e30, float("inf"), float("-inf"), float("nan"), 3.4e38])
+
+
+@settings(max_examples=300, **SET)
+@given(st.binary(max_size=200))
+def test_json_reader_survives_arbitrary_bytes(raw):
+    """Any byte string: RTW_OK or RTW_E_INVALID, never a crash, and nothing written through the NULL outputs."""
+    L = R.lib()
+    ns = C.c_uint32(12345)
+    rc = L.rtw_scene_from_json(raw, len(raw), None, 0, C.byref(ns), None, 0, None, None, 0, None)
+    assert rc in (0, -1)
+
+
+json_number = st.one_of(st.integers(-10**6, 10**6), finite, st.sampled_from(["1e400", "-1e400", "1e-400", "00", "1.", ".5", "+1", "0x10", "NaN", "Infinity"]))
+
+
+@settings(max_examples=200, **SET)
+@given(st.lists(st.tuples(json_number, json_number, json_number, json_number), max_size=4), st.integers(0, 3), st.integers(0, 3), st.integers(0, 5))
+def test_json_reader_on_structurally_valid_documents(spheres, row, col, n_img):
+    """Well-formed objects with hostile numbers and inconsistent texture dimensions: parsed or rejected, counts consistent."""
+    def num(x):
+        return x if isinstance(x, str) else repr(x)
+    items = []
+    for a, b, c, d in spheres:
+        img = ",".join('{"x":1,"y":1,"z":1}' for _ in range(n_img))
+        items.append('{"origin":{"x":%s,"y":%s,"z":%s},"radius":%s,"col_mod":{"x":1,"y":1,"z":1},"material":{"metallicness":0,"opacity":0,"ir":1},'
+                     '"texture":{"row":%d,"col":%d,"img":[%s]}}' % (num(a), num(b), num(c), num(d), row, col, img))
+    raw = ('{"spheres":[' + ",".join(items) + "]}").encode()
+    L = R.lib()
+    ns, nt, nx = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = L.rtw_scene_from_json(raw, len(raw), None, 0, C.byref(ns), None, 0, C.byref(nt), None, 0, C.byref(nx))
+    assert rc in (0, -1)
+    if rc == 0:
+        assert ns.value == len(spheres) and nx.value == nt.value * row * col
+        if spheres:
+            assert 1 <= row and 1 <= col and n_img >= row * col
+        sp = (R.RtwSphere * max(1, ns.value))()
+        tx = (R.RtwTexture * max(1, nt.value))()
+        tl = np.zeros((max(1, nx.value), 3), np.float32)
+        assert L.rtw_scene_from_json(raw, len(raw), sp, ns.value, C.byref(ns), tx, nt.value, C.byref(nt),
+                                     tl.ctypes.data_as(C.POINTER(C.c_float)), nx.value, C.byref(nx)) == 0
+        # too little capacity is refused, not overrun
+        if ns.value:
+            assert L.rtw_scene_from_json(raw, len(raw), sp, ns.value - 1, C.byref(ns), tx, nt.value, C.byref(nt),
+                                         tl.ctypes.data_as(C.POINTER(C.c_float)), nx.value, C.byref(nx)) == -1
+
+
+sphere_st = st.tuples(st.one_of(finite, weird), st.one_of(finite, weird), st.one_of(finite, weird),
+                      st.one_of(st.floats(min_value=0.0, max_value=1e3, width=32), weird),
+                      st.one_of(st.just(0.0), st.floats(min_value=-50, max_value=50, width=32)))
+
+
+@settings(max_examples=150, **SET)
+@given(st.lists(sphere_st, min_size=0, max_size=60), st.floats(min_value=-2, max_value=2, width=32), st.floats(min_value=-2, max_value=2, width=32))
+def test_bvh_builder_on_hostile_scenes(items, t0, t1):
+    """Zero / huge / non-finite radii and centres, coincident spheres, any time range: the builder terminates, never exceeds the device
+    stack, and its self-check either passes or says RTW_E_INVALID (non-finite input) -- it must not crash or loop."""
+    sp = []
+    for x, y, z, r, vy in items:
+        s = R.Sphere.with_albedo((0.0, 0.0, 0.0), 1.0, (0.5, 0.5, 0.5))
+        s.pod.center[0], s.pod.center[1], s.pod.center[2], s.pod.radius, s.pod.velocity[1] = x, y, z, r, vy
+        sp.append(s)
+    sc = R.Scene(sp)
+    nn, depth, nbig, f16 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = R.lib().rtw_bvh_validate(C.byref(sc.pod), float(t0), float(t1), C.byref(nn), C.byref(depth), C.byref(nbig), C.byref(f16))
+    assert rc in (0, -1)
+    assert depth.value <= 24 and nn.value <= max(0, len(items) - 1) and nbig.value <= 16
+    clean = all(math.isfinite(v) and abs(v) < 1e6 for it in items for v in it)
+    if clean:
+        assert rc == 0
+
+
+@settings(max_examples=300, **SET)
+@given(st.integers(0, 5000), st.integers(0, 70), st.integers(0, 40), st.integers(0, 40))
+def test_part_rows_matches_its_definition(height, row_block, index, count):
+    got = R.lib().rtw_part_rows(height, row_block, index, count)
+    if count <= 1:
+        want = height
+    elif row_block == 0 or index >= count:
+        want = 0
+    else:
+        want = sum(1 for r in range(height) if (r // row_block) % count == index)
+    assert got == want
+    if count > 1 and row_block:
+        assert sum(R.lib().rtw_part_rows(height, row_block, i, count) for i in range(count)) == height
+
+
+@settings(max_examples=200, **SET)
+@given(st.lists(st.one_of(st.floats(width=32), weird), min_size=1, max_size=64))
+def test_quantisers_on_any_float(vals):
+    x = np.array(vals, np.float32)
+    a, b = R.quantize_u8(x), R.quantize_u8_rust2(x)
+    assert a.dtype == np.uint8 and a.shape == x.shape and b.shape == x.shape
+    ok = np.isfinite(x) & (x >= 0) & (x <= 1)
+    v = (x[ok] * np.float32(255.0)).astype(np.float64)     # write_img.rs:11-15: (c * 255.0).clamp(0, 255).round() as u8, in f32
+    assert np.array_equal(a[ok], np.floor(v + 0.5).astype(np.uint8))
+    assert (a[x >= 1] == 255).all() and (a[x <= 0] == 0).all() and (a[np.isnan(x)] == 0).all()
+
+
+@settings(max_examples=200, **SET)
+@given(st.integers(1, 4000), st.integers(1, 4000), st.one_of(st.none(), st.floats(min_value=1.0, max_value=179.0, width=32)),
+       st.tuples(finite, finite, finite), st.one_of(st.none(), st.floats(min_value=0.0, max_value=10.0, width=32)))
+def test_viewport_constructor_equals_the_oracle_twin(w, h, vfov, direction, lens):
+    """rtw_viewport_new_from_res (host mirror of Viewport::new, viewport.rs:308-428) == the oracle's independent restatement,
+    field for field and bit for bit, for arbitrary (also degenerate) look directions."""
+    from tests import oracle_binding as O
+    cam, hh = R.RtwCamera(), C.c_uint32()
+    rc = R.lib().rtw_viewport_new_from_res(w, h, R._f1(vfov), None, R._fptr(R._f3(direction)), None, R._f1(lens), C.byref(cam), C.byref(hh))
+    assert rc == 0
+    ocam, oh = O.viewport_new(w, np.float32(w) / np.float32(h), vfov=vfov, direction=direction, lens_radius=lens)
+    a, b = np.frombuffer(bytes(cam), np.float32), np.frombuffer(bytes(ocam), np.float32)
+    both_nan = np.isnan(a) & np.isnan(b)               # (a zero look direction makes unit(vup x w) 0/0: any NaN equals any NaN here)
+    assert np.array_equal(a.view(np.uint32)[~both_nan], b.view(np.uint32)[~both_nan]) and hh.value == oh
