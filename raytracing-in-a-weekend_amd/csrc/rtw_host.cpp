@@ -530,8 +530,9 @@ struct Builder {
                 Box bins[NB]; uint32_t cnt[NB];
                 for (int b = 0; b < NB; b++) { box_empty(bins[b]); cnt[b] = 0; }
                 for (uint32_t i = first; i < first + count; i++) {
-                    int b = (int)((prims[i].cen[ax] - cb.lo[ax]) / ext * NB);
-                    b = std::min(std::max(b, 0), NB - 1);
+                    // (clamped BEFORE the conversion: non-finite centres make this NaN or +-inf, and float -> int of those is undefined)
+                    const float fb = (prims[i].cen[ax] - cb.lo[ax]) / ext * NB;
+                    const int b = fb >= 0.0f ? (fb < (float)NB ? (int)fb : NB - 1) : 0;
                     box_grow(bins[b], prims[i].box); cnt[b]++;
                 }
                 float right_area[NB]; uint32_t right_cnt[NB];
