@@ -56,9 +56,9 @@ struct rtw_ctx {
     uint32_t opt_blocks_per_cu = 0;
     uint32_t opt_list_walk_max = RTW_LIST_WALK_MAX_DEFAULT;
 
-    // caches of per-call driver queries (each costs tens of microseconds: visible on small frames)
+    // cache of a per-call driver query (tens of microseconds: visible on small frames)
     std::map<std::pair<const void *, uint32_t>, uint32_t> occupancy;    // (kernel, dynamic LDS bytes) -> resident workgroups per CU
-    const void *attr_ptr = nullptr; bool attr_on_device = false; int attr_device = -1;   // last out_rgb classified
+    bool attr_on_device = false; int attr_device = -1;   // memory kind of this call's out_rgb
     // the render in flight between render_enqueue and render_wait
     struct Pending {
         bool active = false;
@@ -419,14 +419,14 @@ static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, 
 
     // destination: the kernels write compact rows either straight into the caller's device buffer or into the context's
     const size_t out_bytes = (size_t)n_rows * p->width * 3 * sizeof(float);
-    if (c->attr_ptr != out.base) {
+    // (asked on every call, a few microseconds: the same address can be host memory in one call and device memory in the next)
+    {
         hipPointerAttribute_t attr;
         c->attr_on_device = false; c->attr_device = -1;
         if (hipPointerGetAttributes(&attr, out.base) == hipSuccess) {
             c->attr_on_device = attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
             c->attr_device = attr.device;
         } else (void)hipGetLastError();
-        c->attr_ptr = out.base;
     }
     const bool direct = c->attr_on_device && c->attr_device == c->device && !(out.scatter && p->part_count > 1);
     if (direct) a.out = out.base;
