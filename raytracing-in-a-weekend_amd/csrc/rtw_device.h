@@ -204,9 +204,22 @@ struct DevInstance {
     uint32_t first_sphere, n_spheres, first_quad, n_quads;
     float tr[3]; float density;
     float back[6]; float fwd[6];          // asin, acos, bsin, bcos, csin, ccos
+    // the four coefficient expressions of Vec3::rotated that involve the angles alone (vec3.rs:173-178), evaluated once on the host
+    // with the same f32 operations in the same order:  asin*bsin*ccos - asin*ccos,  acos*bsin*ccos + asin*csin,
+    // asin*bsin*csin + acos*ccos,  acos*bsin*csin - asin*ccos
+    float back_k[4]; float fwd_k[4];
     uint32_t medium; uint32_t pad[3];
 };
-static_assert(sizeof(DevInstance) == 96, "DevInstance is six f4 rows");
+static_assert(sizeof(DevInstance) == 128, "DevInstance is eight f4 rows");
+
+// (host side of the above; __host__ __device__ so that both compilers see one definition)
+__host__ __device__ __forceinline__ void rotation_coefficients(const float *q, float *k) {
+    const float as = q[0], ac = q[1], bs = q[2], cs = q[4], cc = q[5];
+    k[0] = as * bs * cc - as * cc;
+    k[1] = ac * bs * cc + as * cs;
+    k[2] = as * bs * cs + ac * cc;
+    k[3] = ac * bs * cs - as * cc;
+}
 
 struct DevGeom {                          // everything of `Scene` that is not a top-level sphere
     const DevQuad *quads;
@@ -346,12 +359,12 @@ struct GeomHit {
     v3 emitted;
 };
 
-// Vec3::rotated (vec3.rs:161-181) as written; q = {asin, acos, bsin, bcos, csin, ccos}
-__device__ __forceinline__ v3 rotated(v3 a, const float *q) {
+// Vec3::rotated (vec3.rs:161-181) as written; q = {asin, acos, bsin, bcos, csin, ccos}, k = rotation_coefficients(q)
+__device__ __forceinline__ v3 rotated(v3 a, const float *q, const float *k) {
     const float as = q[0], ac = q[1], bs = q[2], bc = q[3], cs = q[4], cc = q[5];
     v3 o;
-    o.x = a.x * bc * cc + a.y * (as * bs * cc - as * cc) + a.z * (ac * bs * cc + as * cs);
-    o.y = a.x * bc * cs + a.y * (as * bs * cs + ac * cc) + a.z * (ac * bs * cs - as * cc);
+    o.x = a.x * bc * cc + a.y * k[0] + a.z * k[1];
+    o.y = a.x * bc * cs + a.y * k[2] + a.z * k[3];
     o.z = a.x * -bs + a.y * as * bc + a.z * ac * bc;
     return o;
 }
@@ -387,6 +400,7 @@ __device__ __forceinline__ void quad_test(const DevScene &sc, const DevQuad *qua
     if (__builtin_fabsf(denominator) <= 1e-8f) return;
     const float t = (r0.w - dot(normal, o)) / denominator;
     if (t < mint || t > maxt) return;
+    if (found && !(h.t > t)) return;                           // cannot replace the current hit (`min_hit > i` is strict): skip the interior test
     const f4 r1 = q[1], r2 = q[2], r4 = q[4];
     const v3 point = o + d * t;
     const v3 planar = point - mk(r0.x, r0.y, r0.z);
@@ -395,7 +409,6 @@ __device__ __forceinline__ void quad_test(const DevScene &sc, const DevQuad *qua
     const v3 uxp = mk(qu.y * planar.z - qu.z * planar.y, qu.z * planar.x - qu.x * planar.z, qu.x * planar.y - qu.y * planar.x);
     const float alfa = dot(w, pxv), beta = dot(w, uxp);
     if (alfa < 0.0f || alfa > 1.0f || beta < 0.0f || beta > 1.0f) return;
-    if (found && !(h.t > t)) return;
     const f4 r5 = q[5], r6 = q[6];
     // (a scalar copy first: __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 with this
     //  toolchain -- seen in the ISA as the texture id compared against w.x)
@@ -470,7 +483,7 @@ __device__ __forceinline__ bool geom_closest(const DevScene &sc, const DevGeom &
     for (uint32_t i = 0; i < g.n_inst; ++i) {                 // Instance::collision_normal (instance.rs:250-310)
         const DevInstance in = g.inst[i];
         const v3 tr = ld3(in.tr);
-        const v3 lo = rotated(o - tr, in.back), ld = rotated(d, in.back);
+        const v3 lo = rotated(o - tr, in.back, in.back_k), ld = rotated(d, in.back, in.back_k);
         GeomHit c;
         if (!instance_members(sc, g, in, lo, ld, tm, mint, maxt, c, n_sph, n_quad)) continue;
         if (in.medium == RTW_MEDIUM_CONST_DENSITY) {           // const_density (:24-26)
@@ -483,8 +496,8 @@ __device__ __forceinline__ bool geom_closest(const DevScene &sc, const DevGeom &
                 c.normal = random_unit_vec(rng);
             }
         }
-        c.point = rotated(c.point, in.fwd) + tr;
-        c.normal = rotated(c.normal, in.fwd);
+        c.point = rotated(c.point, in.fwd, in.fwd_k) + tr;
+        c.normal = rotated(c.normal, in.fwd, in.fwd_k);
         if (!ifound || ih.t > c.t) { ih = c; ifound = true; }
     }
     if (ifound && (!found || h.t > ih.t)) { h = ih; won = true; }

@@ -260,6 +260,7 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
                 d.back[2 * k] = std::sin(-in.rotation[k]); d.back[2 * k + 1] = std::cos(-in.rotation[k]);   // rotated(-self.rotation) (instance.rs:258)
                 d.fwd[2 * k] = std::sin(in.rotation[k]);   d.fwd[2 * k + 1] = std::cos(in.rotation[k]);     // vec3.rs:163-170
             }
+            rotation_coefficients(d.back, d.back_k); rotation_coefficients(d.fwd, d.fwd_k);
         }
         if ((rc = upload(&c->d_quads, quads)) || (rc = upload(&c->d_iquads, iquads)) || (rc = upload(&c->d_inst, inst)) ||
             (rc = upload(&c->d_igeom, igeom)) || (rc = upload(&c->d_ivel, ivel)) || (rc = upload(&c->d_imat, imat))) { free_scene(c); return rc; }
@@ -327,8 +328,21 @@ static int scatter_rows(rtw_ctx *c, const float *src, float *dst, uint32_t width
     return RTW_OK;
 }
 
-// Launch one render on the context's stream; nothing here waits for the GPU (apart from a first-use hipMalloc).
+static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out);
+
+// Launch one render on the context's stream; nothing here waits for the GPU (apart from a first-use hipMalloc).  On failure nothing of
+// this call is left running: whatever was already launched is waited for, so the caller may free or reuse its buffers at once.
 static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out) {
+    const int rc = render_enqueue_impl(c, cam, p, out);
+    if (rc != RTW_OK && c && c->stream && !c->pend.active) {
+        const int keep = g_last_hip;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) (void)hipGetLastError();
+        g_last_hip = keep;
+    }
+    return rc;
+}
+
+static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out) {
     if (!c || !cam || !p || !out.base) return RTW_E_INVALID;
     if (c->pend.active) return RTW_E_INVALID;
     if (!c->has_scene) return RTW_E_NO_SCENE;
