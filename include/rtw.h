@@ -266,9 +266,12 @@ enum {
                                      rendered in bands of tile rows, a budget below one tile row fails with RTW_E_NOMEM  */
     RTW_OPT_LDS_GEOM         = 3, /* sphere {centre, r^2} in LDS next to the f16 nodes: -1 auto (default), 0 off, 1 on   */
     RTW_OPT_BLOCKS_PER_CU    = 4, /* resident workgroups per CU of the persistent grid: 0 auto (default), 1..8           */
-    RTW_OPT_LIST_WALK_MAX    = 5  /* RTW_ACCEL_BVH requests for scenes with at most this many spheres walk the list
+    RTW_OPT_LIST_WALK_MAX    = 5, /* RTW_ACCEL_BVH requests for scenes with at most this many spheres walk the list
                                      instead (result-invariant; the traversal scheduler only costs there).  Default:
                                      the measured crossover; 0 = always use the tree                     */
+    RTW_OPT_TILE_ORDER       = 6  /* order in which the 8x8 tiles enter the work queue: 0 raster; 1 groups of 8 tiles
+                                     scattered over the frame; 2 (default) = 1 with the cheapest ~3 % of the tiles (sky, then ground only, judged
+                                     from the tile's centre ray) moved to the end of the queue; 3 reverse raster                */
 };
 int  rtw_ctx_set_option(rtw_ctx *ctx, uint32_t key, double value);
 
@@ -327,6 +330,10 @@ int rtw_box_quads(const float a[3], const float b[3], const float *mat3, const f
  * host, the products in the reference's written order (including its non-orthogonal terms for rotations about more than
  * one axis). */
 void rtw_vec3_rotated(const float v[3], const float rot[3], float out[3]);
+/* The tile permutation RTW_OPT_TILE_ORDER = mode uses for a whole width x height frame of this camera (host only; for tests and
+ * tools): order[q] = index (row-major over the ceil(width/8) x ceil(height/8) tiles) of the tile the queue hands out q-th. */
+int rtw_tile_order(uint32_t mode, uint32_t width, uint32_t height, const RtwCamera *cam, const RtwScene *scene,
+                   uint32_t *order, uint32_t cap);
 /* Rows a partition owns (see RtwParams). */
 uint32_t rtw_part_rows(uint32_t height, uint32_t row_block, uint32_t part_index, uint32_t part_count);
 /* write_img_f32 quantisation: round(clamp(c*255, 0, 255)) (Rust/src/write_img.rs:11-15). */

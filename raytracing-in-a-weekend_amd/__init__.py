@@ -37,7 +37,7 @@ SAMPLER_ROW, SAMPLER_STRATIFIED, SAMPLER_CENTRES, SAMPLER_NO_RAND = 0, 1, 2, 3
 ACCEL_BRUTE, ACCEL_BVH = 0, 1
 FLAG_RECURSIVE_ORDER, FLAG_CPP_DIELECTRIC, FLAG_GLOBAL_NODES, FLAG_CPP_DIFFUSE, FLAG_CHUNK_SUMS = 1, 2, 4, 8, 16
 FLAG_CPP = FLAG_CPP_DIELECTRIC | FLAG_CPP_DIFFUSE      # what Viewport::RenderGPU of the C++ tree asks for
-OPT_CHUNK_LEN, OPT_SAMPLE_BANK_GB, OPT_LDS_GEOM, OPT_BLOCKS_PER_CU, OPT_LIST_WALK_MAX = 1, 2, 3, 4, 5
+OPT_CHUNK_LEN, OPT_SAMPLE_BANK_GB, OPT_LDS_GEOM, OPT_BLOCKS_PER_CU, OPT_LIST_WALK_MAX, OPT_TILE_ORDER = 1, 2, 3, 4, 5, 6
 SCENE_C1, SCENE_C2, SCENE_C4, SCENE_C5, SCENE_METAL_TEST, SCENE_QUAD_TEST, SCENE_PRESENTATION, SCENE_FIRST_FRAME = 1, 2, 4, 5, 6, 7, 8, 9
 MEDIUM_SURFACE, MEDIUM_CONST_DENSITY = 0, 1
 
@@ -154,6 +154,7 @@ def lib() -> C.CDLL:
     L.rtw_sphere_new_with_texture.argtypes = [fp, C.c_float, fp, fp, fp, C.c_int32, C.POINTER(RtwSphere)]
     L.rtw_vec3_rotated.restype = None
     L.rtw_vec3_rotated.argtypes = [fp, fp, fp]
+    L.rtw_tile_order.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RtwCamera), C.POINTER(RtwScene), C.POINTER(C.c_uint32), C.c_uint32]
     L.rtw_part_rows.restype = C.c_uint32
     L.rtw_part_rows.argtypes = [C.c_uint32] * 4
     L.rtw_quantize_u8.restype = None

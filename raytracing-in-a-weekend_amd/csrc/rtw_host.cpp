@@ -669,6 +669,117 @@ void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end,
 
 } // namespace rtw
 
+// ---- queue order of the tiles ------------------------------------------------------------------------------------------------
+namespace rtw {
+namespace {
+uint32_t gcd_u32(uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; }
+// q -> (q * m) % n with m near n / golden ratio and coprime to n: a bijection that sends neighbours far apart
+std::vector<uint32_t> scatter_perm(uint32_t n) {
+    std::vector<uint32_t> v(n);
+    if (n < 3u) { for (uint32_t q = 0; q < n; q++) v[q] = q; return v; }
+    uint32_t m = (uint32_t)((double)n * 0.6180339887) | 1u;
+    while (gcd_u32(m, n) != 1u) m += 2u;
+    for (uint32_t q = 0; q < n; q++) v[q] = (uint32_t)(((uint64_t)q * m) % n);
+    return v;
+}
+bool ray_hits_box(const double o[3], const double d[3], const float lo[3], const float hi[3]) {
+    double t0 = 0.0, t1 = 1e300;
+    for (int k = 0; k < 3; k++) {
+        if (d[k] == 0.0) { if (o[k] < lo[k] || o[k] > hi[k]) return false; continue; }
+        double a = (lo[k] - o[k]) / d[k], b = (hi[k] - o[k]) / d[k];
+        if (a > b) std::swap(a, b);
+        t0 = std::max(t0, a); t1 = std::min(t1, b);
+    }
+    return t0 <= t1;
+}
+bool ray_hits_sphere(const double o[3], const double d[3], const float c[3], double r) {
+    const double oc[3] = { o[0] - c[0], o[1] - c[1], o[2] - c[2] };
+    const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
+    const double cc = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - r * r, disc = b * b - a * cc;
+    if (!(disc >= 0.0) || !(a > 0.0)) return false;
+    return (-b + std::sqrt(disc)) / a > 0.0;          // some part of the sphere lies ahead of the origin
+}
+} // namespace
+
+void scene_cull_from_bvh(const BvhBuild &bb, const RtwSphere *spheres, SceneCull &out) {
+    out = SceneCull{};
+    for (uint32_t i : bb.big) if (out.n_big < 16u) {
+        float *d = out.big[out.n_big++];
+        d[0] = spheres[i].center[0]; d[1] = spheres[i].center[1]; d[2] = spheres[i].center[2]; d[3] = std::fabs(spheres[i].radius);
+    }
+    if (bb.root == std::numeric_limits<int32_t>::min()) return;
+    out.has_tree = 1u;
+    if (bb.nodes.empty()) {                                   // a single tree sphere: its own box (static part; good enough for a heuristic)
+        const RtwSphere &s = spheres[(uint32_t)~bb.root];
+        for (int k = 0; k < 3; k++) { out.lo[k] = s.center[k] - std::fabs(s.radius) - bb.abs_max * 0.0f; out.hi[k] = s.center[k] + std::fabs(s.radius); }
+        return;
+    }
+    const BvhNode &r = bb.nodes[0];
+    for (int k = 0; k < 3; k++) { out.lo[k] = std::min(r.lo0[k], r.lo1[k]); out.hi[k] = std::max(r.hi0[k], r.hi1[k]); }
+}
+
+void build_tile_order(uint32_t mode, uint32_t tiles_x, uint32_t tiles_y, uint32_t k_base, uint32_t row_block, uint32_t part_index,
+                      uint32_t part_count, const RtwCamera &cam, const SceneCull &cull, std::vector<uint32_t> &order) {
+    const uint32_t n = tiles_x * tiles_y;
+    order.resize(n);
+    if (mode == 3u) { for (uint32_t q = 0; q < n; q++) order[q] = n - 1u - q; return; }
+    if (mode != 1u && mode != 2u) { for (uint32_t q = 0; q < n; q++) order[q] = q; return; }
+    const uint32_t g = 8u, ng = (n + g - 1u) / g;      // (group sizes 2..64 and tails of 1..8 % measure the same within noise: profiles/r02_tile_order.log)
+    const uint32_t pct = 3u;
+    const std::vector<uint32_t> grp = scatter_perm(ng);
+    uint32_t k = 0;
+    for (uint32_t q = 0; q < ng; q++)
+        for (uint32_t i = 0; i < g; i++) { const uint32_t t = grp[q] * g + i; if (t < n) order[k++] = t; }
+    if (mode != 2u || cull.n_other || (!cull.has_tree && !cull.n_big)) return;
+    // cost class of a tile from its centre ray (no lens offset, no jitter): 0 sky, 1 big spheres only (the ground), 2 the sphere field
+    std::vector<uint8_t> cls(n);
+    const double o[3] = { cam.origin[0], cam.origin[1], cam.origin[2] };
+    const uint32_t rb = row_block ? row_block : 1u;
+    for (uint32_t t = 0; t < n; t++) {
+        const uint32_t tcol = t % tiles_x, krow = k_base + (t / tiles_x) * 8u + 4u;      // compact row of the partition -> image row
+        const double j = part_count > 1u ? (double)(((krow / rb) * part_count + part_index) * rb + krow % rb) : (double)krow, i = tcol * 8.0 + 4.0;
+        double d[3];
+        for (int a = 0; a < 3; a++) d[a] = cam.pixel00[a] + cam.delta_u[a] * i + cam.delta_v[a] * j;
+        uint8_t c = 0;
+        if (cull.has_tree && ray_hits_box(o, d, cull.lo, cull.hi)) c = 2;
+        else for (uint32_t b = 0; b < cull.n_big; b++) if (ray_hits_sphere(o, d, cull.big[b], cull.big[b][3])) { c = 1; break; }
+        cls[t] = c;
+    }
+    // the ~3 % cheapest tiles go last: class 0 before class 1, each in the scattered order they already have; class 2 never moves
+    const uint32_t want = std::max(1u, n * pct / 100u);
+    std::vector<char> last(n, 0);
+    uint32_t taken = 0;
+    for (uint8_t c = 0; c < 2 && taken < want; c++)
+        for (uint32_t q = n; q-- > 0 && taken < want;) if (cls[order[q]] == c) { last[order[q]] = 1; taken++; }
+    std::vector<uint32_t> head, tail;
+    head.reserve(n); tail.reserve(taken);
+    // (the tail runs from the more expensive of the cheap tiles to the cheapest: ground-only tiles, then sky)
+    for (uint32_t q = 0; q < n; q++) if (!last[order[q]]) head.push_back(order[q]);
+    for (uint8_t c = 2; c-- > 0;) for (uint32_t q = 0; q < n; q++) if (last[order[q]] && cls[order[q]] == c) tail.push_back(order[q]);
+    head.insert(head.end(), tail.begin(), tail.end());
+    order.swap(head);
+}
+} // namespace rtw
+
+// Exposed for the CPU tests: the permutation RTW_OPT_TILE_ORDER = mode would use for a whole frame of this camera.
+extern "C" int rtw_tile_order(uint32_t mode, uint32_t width, uint32_t height, const RtwCamera *cam, const RtwScene *scene, uint32_t *order, uint32_t cap) {
+    using namespace rtw;
+    if (!cam || !order || width == 0 || height == 0) return RTW_E_INVALID;
+    const uint32_t tx = (width + 7) / 8, ty = (height + 7) / 8;
+    if ((uint64_t)tx * ty > cap) return RTW_E_INVALID;
+    SceneCull cull;
+    if (scene && scene->n_spheres && scene->spheres) {
+        BvhBuild bb;
+        build_bvh(scene->spheres, scene->n_spheres, cam->time0, cam->time0 + cam->shutter, bb);
+        scene_cull_from_bvh(bb, scene->spheres, cull);
+        cull.n_other = scene->n_quads + scene->n_instances;
+    }
+    std::vector<uint32_t> v;
+    build_tile_order(mode, tx, ty, 0, 8, 0, 1, *cam, cull, v);
+    std::copy(v.begin(), v.end(), order);
+    return RTW_OK;
+}
+
 // Host-side self-check of the acceleration structure (no GPU): every tree sphere is reachable exactly once,
 // its time-expanded bounds lie inside the box its parent stores for it and inside every ancestor's, the f16
 // copy (when present) contains the f32 boxes, depth <= RTW_BVH_STACK, big + tree spheres == all spheres.

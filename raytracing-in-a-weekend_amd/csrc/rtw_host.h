@@ -58,4 +58,29 @@ struct BvhBuild {
 // reference's own AABB ignores velocity (aabb/aabb.rs:27-39) and so culls moving spheres wrongly.
 void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end, BvhBuild &out);
 
+// ---- queue order of the 8x8 tiles (RTW_OPT_TILE_ORDER) -------------------------------------------------------------------
+// What the ordering heuristic may know about the scene: the spheres kept outside the tree (the ground) and the root box of
+// the tree's spheres.  n_other != 0 (quads / instances present) switches the cheap-tile guess off.
+struct SceneCull {
+    float big[16][4];            // centre, radius
+    uint32_t n_big = 0;
+    uint32_t has_tree = 0;
+    float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };   // root box of the tree (time-expanded)
+    uint32_t n_other = 0;
+};
+// fills has_tree / lo / hi from a built tree
+void scene_cull_from_bvh(const BvhBuild &bb, const RtwSphere *spheres, SceneCull &out);
+struct TileOrderKey {            // everything the order depends on (compared bytewise)
+    uint32_t mode, tiles_x, tiles_y, k_base, row_block, part_index, part_count, scene_serial;
+    RtwCamera cam;
+};
+// mode 1: groups of 8 consecutive tiles scattered over the frame by a multiplicative bijection (waves then work on a mix of cheap and
+//         expensive image regions at any time instead of all on the same band);
+// mode 2: mode 1, and the cheapest ~3 % of the tiles -- those whose centre ray misses the tree's root box (and, first of all,
+//         every big sphere too: sky) -- moved to the END of the queue, so that a launch ends on short paths;
+// mode 3: reverse raster (bottom rows first).
+// `order` receives a permutation of [0, tiles_x * tiles_y).  The image never depends on it.
+void build_tile_order(uint32_t mode, uint32_t tiles_x, uint32_t tiles_y, uint32_t k_base, uint32_t row_block, uint32_t part_index,
+                      uint32_t part_count, const RtwCamera &cam, const SceneCull &cull, std::vector<uint32_t> &order);
+
 } // namespace rtw

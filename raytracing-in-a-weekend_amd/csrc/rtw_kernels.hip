@@ -70,6 +70,7 @@ struct Reserve {                             // wave-uniform
     uint32_t next, end;                      // items [next, end) of ONE 64-item block: the 64 pixels of one (tile, chunk) unit
     uint32_t i0, k0;                         // the block's tile: first column, first compact row
     uint32_t s0, s1;                         // the block's chunk: samples [s0, s1)
+    uint32_t unit;                           // tile * n_chunks + chunk: the block's place in the sample bank
 };
 
 // Pull the next work item for the lanes with `need` set.  Must be called by all lanes of the wave
@@ -89,7 +90,10 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
         // Work unit = (8x8 tile, chunk of chunk_len samples, pixel of the tile); the units of one tile are consecutive.  The
         // block's tile and chunk are the same for its 64 items: the three integer divisions run once per block, here.
         const uint32_t u = rs.next >> 6;
-        const uint32_t tile = u / A.n_chunks, chunk = u - tile * A.n_chunks;
+        const uint32_t qt = u / A.n_chunks, chunk = u - qt * A.n_chunks;
+        // queue position -> tile: raster order, or any permutation the host supplies (RTW_OPT_TILE_ORDER)
+        const uint32_t tile = A.tile_order ? A.tile_order[qt] : qt;
+        rs.unit = tile * A.n_chunks + chunk;
         const uint32_t trow = tile / A.tiles_x, tcol = tile - trow * A.tiles_x;
         rs.i0 = tcol * 8u;
         rs.k0 = A.k_base + trow * 8u;
@@ -117,7 +121,7 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
     px.rng_base = rng_pixel_base(A.seed_lo, A.seed_hi, px.j * A.width + px.i);
     px.s = rs.s0;
     px.s_end = rs.s1;
-    px.slot = (w >> 6) * 64u * A.bank_len + (w & 63u);            // [unit][sample of chunk][pixel of tile]: lanes that finish the same
+    px.slot = rs.unit * 64u * A.bank_len + (w & 63u);            // [unit][sample of chunk][pixel of tile]: lanes that finish the same
                                                                    // sample of neighbouring pixels together fill whole sectors
     return px.s < px.s_end;
 }
@@ -379,7 +383,7 @@ template <bool MOVING, int SPEC, bool GEOM>
 __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 4 : 1) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
-    Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = 0;
+    Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
     uint32_t n_seg = 0, n_rays = 0, n_isph = 0, n_quad = 0;
 
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
                       F_DONE = 8u };     // a finished path waits for the next SHADE step to bank it
     uint32_t fl = 0u;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
-    Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = 0;
+    Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = 0;
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
     Trav tr; tr.node = (int)Code<stack_t>::END; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.selx = tr.sely = tr.selz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <new>
 #include <utility>
@@ -47,6 +48,11 @@ struct rtw_ctx {
     unsigned long long *h_stats = nullptr;   // pinned: the counter read-back is a true async copy
     float *d_out = nullptr;
     size_t d_out_cap = 0;
+    uint32_t *d_order = nullptr;         // RTW_OPT_TILE_ORDER: queue position -> tile, valid for order_key
+    size_t d_order_cap = 0;
+    TileOrderKey order_key{};
+    SceneCull cull{};                    // what the tile-order heuristic knows about the scene (host copy, set by rtw_ctx_set_scene)
+    uint32_t scene_serial = 0;           // bumped by every rtw_ctx_set_scene
     float *d_samples = nullptr;          // per-sample radiance bank (see render_enqueue)
     size_t d_samples_cap = 0;
     // options (rtw_ctx_set_option)
@@ -55,6 +61,7 @@ struct rtw_ctx {
     int opt_lds_geom = -1;
     uint32_t opt_blocks_per_cu = 0;
     uint32_t opt_list_walk_max = RTW_LIST_WALK_MAX_DEFAULT;
+    uint32_t opt_tile_order = 2;         // measured: profiles/r02_tile_order.log
 
     // cache of a per-call driver query (tens of microseconds: visible on small frames)
     std::map<std::pair<const void *, uint32_t>, uint32_t> occupancy;    // (kernel, dynamic LDS bytes) -> resident workgroups per CU
@@ -190,6 +197,7 @@ void rtw_ctx_destroy(rtw_ctx *c) {
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_samples) (void)hipFree(c->d_samples);
+    if (c->d_order) (void)hipFree(c->d_order);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -285,6 +293,9 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     c->bvh.big_index = (const uint32_t *)c->d_big_index; c->bvh.n_big = (uint32_t)bb.big.size();
     c->bvh.root = bb.root; c->bvh.depth = bb.depth;
     c->bvh_ok = bb.depth <= RTW_BVH_STACK;        // build_bvh guarantees it; a deeper tree would overflow the per-lane LDS stack
+    c->scene_serial++;
+    scene_cull_from_bvh(bb, s->spheres, c->cull);
+    c->cull.n_other = s->n_quads + s->n_instances;
     c->t_begin = std::fmin(t_begin, t_end); c->t_end = std::fmax(t_begin, t_end);
     c->bvh.cx = bb.centre[0]; c->bvh.cy = bb.centre[1]; c->bvh.cz = bb.centre[2];
     c->bvh.centre_radius = bb.centre_radius;
@@ -489,8 +500,31 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         a.k_base = tr0 * 8; a.k_end = tr1 * 8 < n_rows ? tr1 * 8 : n_rows;
         a.n_tiles = a.tiles_x * (tr1 - tr0);
         a.total_work = a.n_tiles * a.n_chunks * 64u;              // < 2^32 by the item bound above
+        a.tile_order = nullptr;
+        if (c->opt_tile_order && a.n_tiles > 2u) {
+            // queue order of the tiles (rtw_host.cpp build_tile_order): built once per (mode, frame shape, camera, partition, scene), kept on the device
+            const uint32_t tiles_y = a.n_tiles / a.tiles_x;
+            TileOrderKey key;
+            std::memset(&key, 0, sizeof key);
+            key.mode = c->opt_tile_order; key.tiles_x = a.tiles_x; key.tiles_y = tiles_y; key.k_base = a.k_base;
+            key.row_block = a.row_block; key.part_index = a.part_index; key.part_count = a.part_count; key.cam = *cam; key.scene_serial = c->scene_serial;
+            if (!c->d_order || std::memcmp(&key, &c->order_key, sizeof key) != 0) {
+                std::vector<uint32_t> order;
+                build_tile_order(c->opt_tile_order, a.tiles_x, tiles_y, a.k_base, a.row_block, a.part_index, a.part_count, *cam, c->cull, order);
+                if (c->d_order_cap < order.size()) {
+                    if (c->d_order) (void)hipFree(c->d_order);
+                    c->d_order = nullptr; c->d_order_cap = 0;
+                    HIP_TRY(hipMalloc((void **)&c->d_order, order.size() * sizeof(uint32_t)));
+                    c->d_order_cap = order.size();
+                }
+                HIP_TRY(hipMemcpyAsync(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));          // (`order` is a local: the copy must be done before it goes away; once per frame shape)
+                c->order_key = key;
+            }
+            a.tile_order = c->d_order;
+        }
         // Small launches are latency-bound, not throughput-bound: a lane should own >= ~16 work units before another resident
-        // workgroup per CU pays (gpurun_out/r02_small_frame.log: C1 0.494 -> 0.276 ms with 1 workgroup per CU instead of 6, `First
+        // workgroup per CU pays (profiles/r02_small_frame.log: C1 0.494 -> 0.276 ms with 1 workgroup per CU instead of 6, `First
         // frame` 3.15 -> 2.68 ms with 4; the 1080p frames are indifferent).  An explicit RTW_OPT_BLOCKS_PER_CU wins.
         uint32_t wg_per_cu = per_cu;
         if (c->opt_blocks_per_cu == 0) {
@@ -559,6 +593,7 @@ int rtw_ctx_set_option(rtw_ctx *c, uint32_t key, double v) {
     case RTW_OPT_LDS_GEOM:       if (!(v >= -1.0 && v <= 1.0)) return RTW_E_INVALID; c->opt_lds_geom = (int)v; return RTW_OK;
     case RTW_OPT_BLOCKS_PER_CU:  if (!(v >= 0.0 && v <= 8.0)) return RTW_E_INVALID; c->opt_blocks_per_cu = (uint32_t)v; return RTW_OK;
     case RTW_OPT_LIST_WALK_MAX:  if (!(v >= 0.0 && v <= 4294967295.0)) return RTW_E_INVALID; c->opt_list_walk_max = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_TILE_ORDER:     if (!(v >= 0.0 && v <= 3.0 && v == (double)(uint32_t)v)) return RTW_E_INVALID; c->opt_tile_order = (uint32_t)v; return RTW_OK;
     default: return RTW_E_INVALID;
     }
 }

@@ -396,3 +396,25 @@ def test_rotated_known_answers_of_the_reference():
         a, b = R.vec3_rotated(v, rot), O.rotated(v, rot)
         assert a.tobytes() == b.tobytes()
         assert np.abs(a - np.float32(want)).max() < 1e-7, (v, rot, a, want)
+
+
+def test_tile_order_modes_on_the_bench_frame():
+    """RTW_OPT_TILE_ORDER on the headline frame (1920x1080 = 240 x 135 tiles): 0 raster, 3 reverse raster, 1 groups of 8 consecutive
+    tiles scattered (neighbouring queue positions inside a group stay neighbours on screen, groups jump), 2 the same with the tiles that
+    see only sky / only the ground at the very end of the queue."""
+    scene = R.Scene.generate(R.SCENE_C2)
+    cam, p = R.default_view(R.SCENE_C5)
+    n = 240 * 135
+    buf = (C.c_uint32 * n)()
+    order = {}
+    for mode in (0, 1, 2, 3):
+        assert R.lib().rtw_tile_order(mode, 1920, 1080, C.byref(cam), C.byref(scene.pod), buf, n) == 0
+        order[mode] = np.array(buf[:])
+        assert np.array_equal(np.sort(order[mode]), np.arange(n))
+    assert np.array_equal(order[0], np.arange(n)) and np.array_equal(order[3], np.arange(n)[::-1])
+    g = order[1].reshape(-1, 8)
+    assert (np.diff(g, axis=1) == 1).all() and (g[:, 0] % 8 == 0).all()                  # groups of 8 consecutive tiles
+    assert np.abs(np.diff(g[:, 0])).min() > 8 * 100                                        # consecutive groups are far apart
+    last = order[2][-(n * 3 // 100):]
+    assert (last // 240).max() < 20 and (order[1][-(n * 3 // 100):] // 240).max() > 100      # the end of the queue is the top of the image (sky, far ground)
+    assert set(order[2][: n - n * 3 // 100]) | set(last) == set(range(n))

@@ -125,3 +125,18 @@ def test_viewport_constructor_equals_the_oracle_twin(w, h, vfov, direction, lens
     a, b = np.frombuffer(bytes(cam), np.float32), np.frombuffer(bytes(ocam), np.float32)
     both_nan = np.isnan(a) & np.isnan(b)               # (a zero look direction makes unit(vup x w) 0/0: any NaN equals any NaN here)
     assert np.array_equal(a.view(np.uint32)[~both_nan], b.view(np.uint32)[~both_nan]) and hh.value == oh
+
+
+@settings(max_examples=120, **SET)
+@given(st.integers(0, 3), st.integers(1, 700), st.integers(1, 400), st.tuples(finite, finite, finite), st.booleans())
+def test_tile_order_is_always_a_permutation(mode, w, h, direction, with_scene):
+    """RTW_OPT_TILE_ORDER: whatever the mode, the frame shape, the camera (also degenerate ones) and the scene, the queue order is a
+    permutation of the tiles -- every tile is handed out exactly once."""
+    cam, hh = R.RtwCamera(), C.c_uint32()
+    assert R.lib().rtw_viewport_new_from_res(w, h, None, None, R._fptr(R._f3(direction)), None, None, C.byref(cam), C.byref(hh)) == 0
+    n = ((w + 7) // 8) * ((h + 7) // 8)
+    out = (C.c_uint32 * n)()
+    scene = R.Scene.generate(R.SCENE_C1) if with_scene else None
+    rc = R.lib().rtw_tile_order(mode, w, h, C.byref(cam), C.byref(scene.pod) if scene else None, out, n)
+    assert rc == 0 and sorted(out[:]) == list(range(n))
+    assert R.lib().rtw_tile_order(mode, w, h, C.byref(cam), None, out, n - 1) == -1          # capacity is checked
