@@ -449,7 +449,9 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 // rho/tau small and gives an early best_t.
 #define RTW_KU 1.4305115e-6f    /* 24 * 2^-24 */
 #ifndef RTW_S_HI
-#define RTW_S_HI 48u            /* lanes waiting in SHADE that trigger a SHADE step (bench frame 48: 26.93, 56: 27.08, 60/64: 26.94 Gsegments/s; the dielectric-heavy C4 frame loses 3 % at 56) */
+#define RTW_S_HI 52u            /* lanes waiting in SHADE that trigger a SHADE step.  Round 1 (raster tile order): 48: 26.93, 56: 27.08, 60/64: 26.94 G segments/s,
+                                   C4 loses 3 % at 56.  Round 2 (scattered tile order, profiles/r02_ab_s_hi.log): 44 / 48 / 52 / 56 = 26.92 / 27.37 / 27.61 / 27.52
+                                   on the bench frame; 52 against 48 on the other configs: C2 +3.6 %, C4 -1.3 %, C5 +0.0 % */
 #endif
 #ifndef RTW_TRAV_UNROLL
 #define RTW_TRAV_UNROLL 3       /* node visits per scheduling decision (1: 13.2, 2: 14.4, 3: 14.9, 4: 14.2 Gsegments/s) */
