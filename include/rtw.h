@@ -261,7 +261,7 @@ int  rtw_render(const RtwCamera *cam, const RtwScene *scene, const RtwParams *pa
 
 /* Tuning knobs of a context (they were process environment variables up to ABI v2).  None of them changes the image. */
 enum {
-    RTW_OPT_CHUNK_LEN        = 1, /* samples per work unit, 1..4096 (default 4)                                          */
+    RTW_OPT_CHUNK_LEN        = 1, /* samples per work unit, 1..4096; 0 = chosen from the size of the launch (default)          */
     RTW_OPT_SAMPLE_BANK_GB   = 2, /* budget of the per-sample radiance bank in GiB (default 48); larger frames are
                                      rendered in bands of tile rows, a budget below one tile row fails with RTW_E_NOMEM  */
     RTW_OPT_LDS_GEOM         = 3, /* sphere {centre, r^2} in LDS next to the f16 nodes: -1 auto (default), 0 off, 1 on   */
@@ -270,8 +270,9 @@ enum {
                                      instead (result-invariant; the traversal scheduler only costs there).  Default:
                                      the measured crossover; 0 = always use the tree                     */
     RTW_OPT_TILE_ORDER       = 6  /* order in which the 8x8 tiles enter the work queue: 0 raster; 1 groups of 8 tiles
-                                     scattered over the frame; 2 (default) = 1 with the cheapest ~3 % of the tiles (sky, then ground only, judged
-                                     from the tile's centre ray) moved to the end of the queue; 3 reverse raster                */
+                                     scattered over the frame; 2 (default) expensive tiles first by a cost estimated from each tile's
+                                     centre ray (sphere field / ground only / sky, nearer first), raster for scenes with quads or
+                                     instances; 3 reverse raster                                                            */
 };
 int  rtw_ctx_set_option(rtw_ctx *ctx, uint32_t key, double value);
 

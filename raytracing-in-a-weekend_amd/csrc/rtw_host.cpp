@@ -682,7 +682,7 @@ std::vector<uint32_t> scatter_perm(uint32_t n) {
     for (uint32_t q = 0; q < n; q++) v[q] = (uint32_t)(((uint64_t)q * m) % n);
     return v;
 }
-bool ray_hits_box(const double o[3], const double d[3], const float lo[3], const float hi[3]) {
+bool ray_hits_box(const double o[3], const double d[3], const float lo[3], const float hi[3], double &t_entry) {
     double t0 = 0.0, t1 = 1e300;
     for (int k = 0; k < 3; k++) {
         if (d[k] == 0.0) { if (o[k] < lo[k] || o[k] > hi[k]) return false; continue; }
@@ -690,14 +690,17 @@ bool ray_hits_box(const double o[3], const double d[3], const float lo[3], const
         if (a > b) std::swap(a, b);
         t0 = std::max(t0, a); t1 = std::min(t1, b);
     }
+    t_entry = t0;
     return t0 <= t1;
 }
-bool ray_hits_sphere(const double o[3], const double d[3], const float c[3], double r) {
+bool ray_hits_sphere(const double o[3], const double d[3], const float c[3], double r, double &t_entry) {
     const double oc[3] = { o[0] - c[0], o[1] - c[1], o[2] - c[2] };
     const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
     const double cc = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - r * r, disc = b * b - a * cc;
     if (!(disc >= 0.0) || !(a > 0.0)) return false;
-    return (-b + std::sqrt(disc)) / a > 0.0;          // some part of the sphere lies ahead of the origin
+    const double sq = std::sqrt(disc);
+    t_entry = std::max(0.0, (-b - sq) / a);
+    return (-b + sq) / a > 0.0;                        // some part of the sphere lies ahead of the origin
 }
 } // namespace
 
@@ -719,45 +722,47 @@ void scene_cull_from_bvh(const BvhBuild &bb, const RtwSphere *spheres, SceneCull
 }
 
 void build_tile_order(uint32_t mode, uint32_t tiles_x, uint32_t tiles_y, uint32_t k_base, uint32_t row_block, uint32_t part_index,
-                      uint32_t part_count, const RtwCamera &cam, const SceneCull &cull, std::vector<uint32_t> &order) {
+                      uint32_t part_count, const RtwCamera &cam, const SceneCull &cull, uint32_t tail_tiles, std::vector<uint32_t> &order) {
     const uint32_t n = tiles_x * tiles_y;
     order.resize(n);
     if (mode == 3u) { for (uint32_t q = 0; q < n; q++) order[q] = n - 1u - q; return; }
     if (mode != 1u && mode != 2u) { for (uint32_t q = 0; q < n; q++) order[q] = q; return; }
-    const uint32_t g = 8u, ng = (n + g - 1u) / g;      // (group sizes 2..64 and tails of 1..8 % measure the same within noise: profiles/r02_tile_order.log)
-    const uint32_t pct = 3u;
+    const uint32_t g = 8u, ng = (n + g - 1u) / g;      // (group sizes 2..64 measure the same within noise: profiles/r02_tile_order.log)
     const std::vector<uint32_t> grp = scatter_perm(ng);
     uint32_t k = 0;
     for (uint32_t q = 0; q < ng; q++)
         for (uint32_t i = 0; i < g; i++) { const uint32_t t = grp[q] * g + i; if (t < n) order[k++] = t; }
     if (mode != 2u || cull.n_other || (!cull.has_tree && !cull.n_big)) return;
-    // cost class of a tile from its centre ray (no lens offset, no jitter): 0 sky, 1 big spheres only (the ground), 2 the sphere field
-    std::vector<uint8_t> cls(n);
+    // Mode 2: longest-processing-time-first by an ESTIMATE of a tile's cost, from its centre ray (no lens offset, no jitter):
+    //   class 2  the ray enters the root box of the tree's spheres: the sphere field -- nearer means larger spheres on screen, more
+    //            pixels that hit one, more inter-reflection: cost falls with the distance at which the ray reaches the ground (a big
+    //            sphere) under the field; rays through the box that never reach it come after those
+    //   class 1  it hits only a sphere kept outside the tree (the ground): one bounce, then mostly sky -- nearer first again
+    //   class 0  it hits nothing: sky
+    // Expensive tiles first, cheap tiles last: the launch ends on short paths (for a camera above the ground looking at the scene this
+    // is close to "bottom rows first"; it follows the camera when that looks elsewhere).  `tail_tiles` is not needed by a full sort.
+    (void)tail_tiles;
+    struct Key { uint8_t cls; float dist; uint32_t tile; };
+    std::vector<Key> keys(n);
     const double o[3] = { cam.origin[0], cam.origin[1], cam.origin[2] };
     const uint32_t rb = row_block ? row_block : 1u;
     for (uint32_t t = 0; t < n; t++) {
         const uint32_t tcol = t % tiles_x, krow = k_base + (t / tiles_x) * 8u + 4u;      // compact row of the partition -> image row
         const double j = part_count > 1u ? (double)(((krow / rb) * part_count + part_index) * rb + krow % rb) : (double)krow, i = tcol * 8.0 + 4.0;
-        double d[3];
-        for (int a = 0; a < 3; a++) d[a] = cam.pixel00[a] + cam.delta_u[a] * i + cam.delta_v[a] * j;
-        uint8_t c = 0;
-        if (cull.has_tree && ray_hits_box(o, d, cull.lo, cull.hi)) c = 2;
-        else for (uint32_t b = 0; b < cull.n_big; b++) if (ray_hits_sphere(o, d, cull.big[b], cull.big[b][3])) { c = 1; break; }
-        cls[t] = c;
+        double d[3], len2 = 0.0;
+        for (int a = 0; a < 3; a++) { d[a] = cam.pixel00[a] + cam.delta_u[a] * i + cam.delta_v[a] * j; len2 += d[a] * d[a]; }
+        const double len = std::sqrt(len2);
+        Key kx; kx.cls = 0; kx.dist = 0.0f; kx.tile = t;
+        // distance along the centre ray to the nearest big sphere (the ground under the sphere field), else to the root box
+        double te = 0.0, big = 1e300, box = 0.0;
+        for (uint32_t b = 0; b < cull.n_big; b++) if (ray_hits_sphere(o, d, cull.big[b], cull.big[b][3], te)) big = std::min(big, te * len);
+        if (cull.has_tree && ray_hits_box(o, d, cull.lo, cull.hi, box)) { kx.cls = 2; kx.dist = (float)(big < 1e300 ? big : box * len + 1e6); }
+        else if (big < 1e300) { kx.cls = 1; kx.dist = (float)big; }
+        if (!(kx.dist == kx.dist)) kx.dist = 0.0f;           // (degenerate cameras)
+        keys[t] = kx;
     }
-    // the ~3 % cheapest tiles go last: class 0 before class 1, each in the scattered order they already have; class 2 never moves
-    const uint32_t want = std::max(1u, n * pct / 100u);
-    std::vector<char> last(n, 0);
-    uint32_t taken = 0;
-    for (uint8_t c = 0; c < 2 && taken < want; c++)
-        for (uint32_t q = n; q-- > 0 && taken < want;) if (cls[order[q]] == c) { last[order[q]] = 1; taken++; }
-    std::vector<uint32_t> head, tail;
-    head.reserve(n); tail.reserve(taken);
-    // (the tail runs from the more expensive of the cheap tiles to the cheapest: ground-only tiles, then sky)
-    for (uint32_t q = 0; q < n; q++) if (!last[order[q]]) head.push_back(order[q]);
-    for (uint8_t c = 2; c-- > 0;) for (uint32_t q = 0; q < n; q++) if (last[order[q]] && cls[order[q]] == c) tail.push_back(order[q]);
-    head.insert(head.end(), tail.begin(), tail.end());
-    order.swap(head);
+    std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.cls != b.cls ? a.cls > b.cls : a.dist < b.dist; });
+    for (uint32_t q = 0; q < n; q++) order[q] = keys[q].tile;
 }
 } // namespace rtw
 
@@ -775,7 +780,7 @@ extern "C" int rtw_tile_order(uint32_t mode, uint32_t width, uint32_t height, co
         cull.n_other = scene->n_quads + scene->n_instances;
     }
     std::vector<uint32_t> v;
-    build_tile_order(mode, tx, ty, 0, 8, 0, 1, *cam, cull, v);
+    build_tile_order(mode, tx, ty, 0, 8, 0, 1, *cam, cull, 0, v);
     std::copy(v.begin(), v.end(), order);
     return RTW_OK;
 }

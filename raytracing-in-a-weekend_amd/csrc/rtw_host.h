@@ -71,16 +71,16 @@ struct SceneCull {
 // fills has_tree / lo / hi from a built tree
 void scene_cull_from_bvh(const BvhBuild &bb, const RtwSphere *spheres, SceneCull &out);
 struct TileOrderKey {            // everything the order depends on (compared bytewise)
-    uint32_t mode, tiles_x, tiles_y, k_base, row_block, part_index, part_count, scene_serial;
+    uint32_t mode, tiles_x, tiles_y, k_base, row_block, part_index, part_count, scene_serial, tail_tiles;
     RtwCamera cam;
 };
 // mode 1: groups of 8 consecutive tiles scattered over the frame by a multiplicative bijection (waves then work on a mix of cheap and
 //         expensive image regions at any time instead of all on the same band);
-// mode 2: mode 1, and the cheapest ~3 % of the tiles -- those whose centre ray misses the tree's root box (and, first of all,
-//         every big sphere too: sky) -- moved to the END of the queue, so that a launch ends on short paths;
+// mode 2: longest-processing-time-first by an estimated cost per tile (class of the tile's centre ray -- sphere field, ground only,
+//         sky -- then distance, nearer first): the launch ends on its cheapest tiles;
 // mode 3: reverse raster (bottom rows first).
 // `order` receives a permutation of [0, tiles_x * tiles_y).  The image never depends on it.
 void build_tile_order(uint32_t mode, uint32_t tiles_x, uint32_t tiles_y, uint32_t k_base, uint32_t row_block, uint32_t part_index,
-                      uint32_t part_count, const RtwCamera &cam, const SceneCull &cull, std::vector<uint32_t> &order);
+                      uint32_t part_count, const RtwCamera &cam, const SceneCull &cull, uint32_t tail_tiles, std::vector<uint32_t> &order);
 
 } // namespace rtw

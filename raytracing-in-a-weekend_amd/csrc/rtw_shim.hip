@@ -56,12 +56,12 @@ struct rtw_ctx {
     float *d_samples = nullptr;          // per-sample radiance bank (see render_enqueue)
     size_t d_samples_cap = 0;
     // options (rtw_ctx_set_option)
-    uint32_t opt_chunk_len = 4;          // tuned on the bench frame: 4-6 is the flat optimum (1: 13.5, 2: 17.0, 4: 17.9, 8: 17.3, 16: 16.8 Gsegments/s)
+    uint32_t opt_chunk_len = 0;          // 0 = auto (render_enqueue); round 1 tuned a fixed 4 on the bench frame (1: 13.5, 2: 17.0, 4: 17.9, 8: 17.3, 16: 16.8 Gsegments/s)
     uint64_t opt_bank_bytes = 48ull << 30;
     int opt_lds_geom = -1;
     uint32_t opt_blocks_per_cu = 0;
     uint32_t opt_list_walk_max = RTW_LIST_WALK_MAX_DEFAULT;
-    uint32_t opt_tile_order = 2;         // measured: profiles/r02_tile_order.log
+    uint32_t opt_tile_order = 2;         // measured: profiles/r02_order_chunk_grid.log
 
     // cache of a per-call driver query (tens of microseconds: visible on small frames)
     std::map<std::pair<const void *, uint32_t>, uint32_t> occupancy;    // (kernel, dynamic LDS bytes) -> resident workgroups per CU
@@ -416,11 +416,17 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     // (12.4 GB for 1920x1080x500) -- the image is rendered in bands of tile rows when that exceeds the budget.
     // RTW_FLAG_CHUNK_SUMS banks one partial sum per unit instead (bank_len = 1 slot per unit and pixel).
     uint32_t chunk_len = (p->flags & RTW_FLAG_CHUNK_SUMS) ? RTW_SUM_CHUNK : c->opt_chunk_len;   // (the summation chunk is part of the image's definition)
+    if (chunk_len == 0) {
+        // auto: the unit length follows the size of the launch (profiles/r02_order_chunk_grid.log).  Long units amortise the per-unit work
+        // (queue, pixel hash, bank addressing) but lengthen the tail of the launch, which is one unit deep: the whole bench frame
+        // (660 units of 4 per lane) runs in 101.0 / 98.5 / 97.4 ms with units of 4 / 6 / 8, an eighth of it (82 per lane) in 13.46 /
+        // 13.34 / 13.55, C2 (51 per lane) in 8.97 / 9.17 / 9.37.  A frame so small that one workgroup per CU is enough (below) gets
+        // units of 2 (C1: 0.276 -> 0.261 ms).
+        const uint64_t units4 = (uint64_t)a.tiles_x * ((n_rows + 7) / 8) * ((a.n_samples + 3) / 4) * 64ull;
+        const uint64_t lanes = (uint64_t)c->n_cu * RTW_BLOCK * 6ull;
+        chunk_len = units4 >= 200ull * lanes ? 8u : units4 >= 64ull * lanes ? 6u : (units4 * 6ull < 16ull * lanes ? 2u : 4u);
+    }
     if (chunk_len > a.n_samples) chunk_len = a.n_samples;
-    // a frame so small that one workgroup per CU is enough (below): halve the unit, the tail of the launch is one unit deep
-    // (C1: 0.276 -> 0.261 ms, profiles/r02_small_frame.log)
-    if (!(p->flags & RTW_FLAG_CHUNK_SUMS) && chunk_len >= 4 &&
-        (uint64_t)a.tiles_x * ((n_rows + 7) / 8) * ((a.n_samples + chunk_len - 1) / chunk_len) * 64ull < (uint64_t)c->n_cu * RTW_BLOCK * 16ull) chunk_len /= 2;
     a.chunk_len = chunk_len;
     a.n_chunks = (a.n_samples + chunk_len - 1) / chunk_len;
     a.bank_len = (p->flags & RTW_FLAG_CHUNK_SUMS) ? 1u : chunk_len;
@@ -501,16 +507,19 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         a.n_tiles = a.tiles_x * (tr1 - tr0);
         a.total_work = a.n_tiles * a.n_chunks * 64u;              // < 2^32 by the item bound above
         a.tile_order = nullptr;
-        if (c->opt_tile_order && a.n_tiles > 2u) {
+        if (c->opt_tile_order && a.n_tiles > 2u && !(c->opt_tile_order == 2u && c->cull.n_other)) {    // (quads / instances: no cost guess, raster order)
             // queue order of the tiles (rtw_host.cpp build_tile_order): built once per (mode, frame shape, camera, partition, scene), kept on the device
             const uint32_t tiles_y = a.n_tiles / a.tiles_x;
             TileOrderKey key;
             std::memset(&key, 0, sizeof key);
             key.mode = c->opt_tile_order; key.tiles_x = a.tiles_x; key.tiles_y = tiles_y; key.k_base = a.k_base;
             key.row_block = a.row_block; key.part_index = a.part_index; key.part_count = a.part_count; key.cam = *cam; key.scene_serial = c->scene_serial;
+            // tiles worth of work in flight when the queue runs dry: four units for every lane of the full grid
+            const uint64_t per_tile = 64ull * a.n_chunks;
+            key.tail_tiles = (uint32_t)std::min<uint64_t>(a.n_tiles, ((uint64_t)c->n_cu * per_cu * RTW_BLOCK * 4ull + per_tile - 1) / per_tile);
             if (!c->d_order || std::memcmp(&key, &c->order_key, sizeof key) != 0) {
                 std::vector<uint32_t> order;
-                build_tile_order(c->opt_tile_order, a.tiles_x, tiles_y, a.k_base, a.row_block, a.part_index, a.part_count, *cam, c->cull, order);
+                build_tile_order(c->opt_tile_order, a.tiles_x, tiles_y, a.k_base, a.row_block, a.part_index, a.part_count, *cam, c->cull, key.tail_tiles, order);
                 if (c->d_order_cap < order.size()) {
                     if (c->d_order) (void)hipFree(c->d_order);
                     c->d_order = nullptr; c->d_order_cap = 0;
@@ -588,7 +597,7 @@ extern "C" {
 int rtw_ctx_set_option(rtw_ctx *c, uint32_t key, double v) {
     if (!c || !(v == v)) return RTW_E_INVALID;
     switch (key) {
-    case RTW_OPT_CHUNK_LEN:      if (!(v >= 1.0 && v <= 4096.0)) return RTW_E_INVALID; c->opt_chunk_len = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_CHUNK_LEN:      if (!(v >= 0.0 && v <= 4096.0)) return RTW_E_INVALID; c->opt_chunk_len = (uint32_t)v; return RTW_OK;
     case RTW_OPT_SAMPLE_BANK_GB: if (!(v > 0.0 && v <= 1048576.0)) return RTW_E_INVALID; c->opt_bank_bytes = (uint64_t)(v * (double)(1ull << 30)); return RTW_OK;
     case RTW_OPT_LDS_GEOM:       if (!(v >= -1.0 && v <= 1.0)) return RTW_E_INVALID; c->opt_lds_geom = (int)v; return RTW_OK;
     case RTW_OPT_BLOCKS_PER_CU:  if (!(v >= 0.0 && v <= 8.0)) return RTW_E_INVALID; c->opt_blocks_per_cu = (uint32_t)v; return RTW_OK;

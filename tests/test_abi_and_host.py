@@ -400,8 +400,8 @@ def test_rotated_known_answers_of_the_reference():
 
 def test_tile_order_modes_on_the_bench_frame():
     """RTW_OPT_TILE_ORDER on the headline frame (1920x1080 = 240 x 135 tiles): 0 raster, 3 reverse raster, 1 groups of 8 consecutive
-    tiles scattered (neighbouring queue positions inside a group stay neighbours on screen, groups jump), 2 the same with the tiles that
-    see only sky / only the ground at the very end of the queue."""
+    tiles scattered (neighbouring queue positions inside a group stay neighbours on screen, groups jump), 2 expensive tiles first by
+    the centre-ray estimate: the sphere field nearest the camera (bottom of this image) first, sky last."""
     scene = R.Scene.generate(R.SCENE_C2)
     cam, p = R.default_view(R.SCENE_C5)
     n = 240 * 135
@@ -415,6 +415,13 @@ def test_tile_order_modes_on_the_bench_frame():
     g = order[1].reshape(-1, 8)
     assert (np.diff(g, axis=1) == 1).all() and (g[:, 0] % 8 == 0).all()                  # groups of 8 consecutive tiles
     assert np.abs(np.diff(g[:, 0])).min() > 8 * 100                                        # consecutive groups are far apart
-    last = order[2][-(n * 3 // 100):]
-    assert (last // 240).max() < 20 and (order[1][-(n * 3 // 100):] // 240).max() > 100      # the end of the queue is the top of the image (sky, far ground)
-    assert set(order[2][: n - n * 3 // 100]) | set(last) == set(range(n))
+    rows = order[2] // 240
+    assert rows[:2000].mean() > 100 and rows[-2000:].mean() < 10                            # near field first, sky (top rows) last
+    # without a scene there is nothing to estimate from: mode 2 keeps the scattered order of mode 1
+    assert R.lib().rtw_tile_order(2, 1920, 1080, C.byref(cam), None, buf, n) == 0 and np.array_equal(np.array(buf[:]), order[1])
+    # a camera that looks UP from below the ground plane region: the estimate follows the camera, not the image rows
+    vp = R.Viewport.new_from_res(1920, 1080, 1, 1, 1.0, vfov=20.0, origin=(13.0, 2.0, 3.0), direction=(-0.9636, -0.1482, -0.2224), vup=(0.0, -1.0, 0.0))
+    cam2 = vp.camera()
+    assert R.lib().rtw_tile_order(2, 1920, 1080, C.byref(cam2), C.byref(scene.pod), buf, n) == 0
+    rows2 = np.array(buf[:]) // 240
+    assert rows2[:2000].mean() < 35 and rows2[-2000:].mean() > 125                           # upside-down image: the near field is at the top now

@@ -361,7 +361,7 @@ def test_sample_bank_bands_and_chunk_lengths(rtw):
             gpu.set_option(R.OPT_CHUNK_LEN, chunk)
             img, st = gpu.render(cam, p)
             assert np.array_equal(img, ref) and st.camera_rays == 200 * 120 * 37, chunk
-        gpu.set_option(R.OPT_CHUNK_LEN, 4)
+        gpu.set_option(R.OPT_CHUNK_LEN, 0)
         gpu.set_option(R.OPT_SAMPLE_BANK_GB, 0.003)          # ~3 MiB: forces several bands (one tile row is 25*10*64*4*12 B = 0.73 MiB)
         img, st = gpu.render(cam, p)
         assert np.array_equal(img, ref) and st.segments == st_ref.segments
@@ -372,7 +372,7 @@ def test_sample_bank_bands_and_chunk_lengths(rtw):
         with pytest.raises(R.RtwError):                      # unknown key / out-of-range value
             gpu.set_option(99, 1)
         with pytest.raises(R.RtwError):
-            gpu.set_option(R.OPT_CHUNK_LEN, 0)
+            gpu.set_option(R.OPT_CHUNK_LEN, -1)
 
 
 def test_example_program_through_the_c_abi(gpu, tmp_path):
