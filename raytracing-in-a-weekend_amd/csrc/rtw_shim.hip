@@ -424,7 +424,8 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         // units of 2 (C1: 0.276 -> 0.261 ms).
         const uint64_t units4 = (uint64_t)a.tiles_x * ((n_rows + 7) / 8) * ((a.n_samples + 3) / 4) * 64ull;
         const uint64_t lanes = (uint64_t)c->n_cu * RTW_BLOCK * 6ull;
-        chunk_len = units4 >= 200ull * lanes ? 8u : units4 >= 64ull * lanes ? 6u : (units4 * 6ull < 16ull * lanes ? 2u : 4u);
+        // (units of 12 from 500 per lane: bench frame 97.8 -> 97.0 ms, C4 386.1 -> 383.7; 16..32 gain C4 another 0.6 % and lose the bench frame 0.3..0.9 %)
+        chunk_len = units4 >= 500ull * lanes ? 12u : units4 >= 200ull * lanes ? 8u : units4 >= 64ull * lanes ? 6u : (units4 * 6ull < 16ull * lanes ? 2u : 4u);
     }
     if (chunk_len > a.n_samples) chunk_len = a.n_samples;
     a.chunk_len = chunk_len;
