@@ -515,6 +515,7 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
             std::memset(&key, 0, sizeof key);
             key.mode = c->opt_tile_order; key.tiles_x = a.tiles_x; key.tiles_y = tiles_y; key.k_base = a.k_base;
             key.row_block = a.row_block; key.part_index = a.part_index; key.part_count = a.part_count; key.cam = *cam; key.scene_serial = c->scene_serial;
+            key.cam.time0 = key.cam.shutter = key.cam.lens_radius = 0.0f;     // (the estimate uses the centre rays only: the frames of a clip share one order)
             // tiles worth of work in flight when the queue runs dry: four units for every lane of the full grid
             const uint64_t per_tile = 64ull * a.n_chunks;
             key.tail_tiles = (uint32_t)std::min<uint64_t>(a.n_tiles, ((uint64_t)c->n_cu * per_cu * RTW_BLOCK * 4ull + per_tile - 1) / per_tile);
