@@ -192,7 +192,7 @@ static PathTrace trace_path(const Scene &S, const RtwCamera &cam, uint32_t i, ui
 struct Costs { double T = 180, L = 230, S = 2800, X = 520, Sbase = 0; };   // cycles per wave-step
 struct Policy {
     int paths = 1;          // paths per lane
-    unsigned s_hi = 48, t_lo = 6, x_hi = 16, burst = 3;
+    unsigned s_hi = 48, t_lo = 6, x_hi = 16, burst = 3, l_hi = 0;   // l_hi != 0: LEAF runs only with >= l_hi lanes (or when nothing traverses)
     bool x_when_any = false;
 };
 struct Lane {
@@ -255,7 +255,7 @@ static Result simulate(const std::vector<std::vector<std::vector<PathTrace>>> &b
                     begin_query(l);
                     state[l] = lane[l].t_done ? 2 : 0;
                 }
-            } else if (nT >= nL) {
+            } else if (P.l_hi ? !(nL >= P.l_hi || nT == 0) : nT >= nL) {
                 unsigned live = nT;
                 for (unsigned u = 0; u < P.burst && live; u++) {
                     R.steps[0]++; R.lanes[0] += live; R.cyc += C.T;
@@ -533,6 +533,14 @@ int main(int argc, char **argv) {
             auto eff = [&](int k) { return R.steps[k] ? R.lanes[k] / (64.0 * R.steps[k]) : 0.0; };
             printf("pool K %3u s_hi %2u x_hi %2u: cyc/seg %7.1f | T %.3f (%4.1f%%) L %.3f (%4.1f%%) S %.3f (%4.1f%%) X %.3f (%4.1f%%)\n", K, sh, xh, R.cyc / R.segments,
                    eff(0), 100 * R.steps[0] * C.T / R.cyc, eff(1), 100 * R.steps[1] * C.L / R.cyc, eff(2), 100 * R.steps[2] * C.S / R.cyc, eff(3), 100 * R.steps[3] * C.X / R.cyc);
+        }
+        return 0;
+    }
+    if (argc > 3 && !strcmp(argv[3], "leaf")) {
+        for (unsigned sh : { 48u, 52u }) for (unsigned lh : { 0u, 8u, 16u, 24u, 32u, 40u, 48u }) {
+            Policy q; q.s_hi = sh; q.l_hi = lh;
+            char nm[96]; snprintf(nm, sizeof nm, "1 path: s_hi %u l_hi %u", sh, lh);
+            report(nm, q);
         }
         return 0;
     }
