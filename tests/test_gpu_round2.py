@@ -350,3 +350,17 @@ def test_tile_order_never_changes_the_image(rtw, mode):
         part, _ = r.render(cam, p)
         rows = [j for j in range(120) if (j // 8) % 3 == 2]
         assert np.array_equal(part, ref[rows])
+
+
+def test_bench_single_process_multi_gpu_path(gpu):
+    """bench.py --devices 0,0,0: the single-process N-GPU path of the bench (rtw_mgpu, frame assembled in GPU 0's HBM by strided
+    copies, no torch.distributed) end to end, with three contexts on this one GPU."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--devices", "0,0,0", "--steps", "1", "--warmup", "1", "--spp", "8", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["value"] > 0 and "rtw_mgpu" in d["config"]["workload"]
+    # three contexts traced the whole frame between them: 1920 x 1080 x 8 camera rays
+    assert abs(d["roofline"]["units_per_launch"]["segments"] * 3 / (1920 * 1080 * 8) - d["config"]["segments_per_camera_ray"]) < 1e-3
