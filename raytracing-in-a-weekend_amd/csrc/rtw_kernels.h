@@ -56,6 +56,7 @@ struct KArgs {
     float bg[3];
     float *out;                   // [rows of the partition][width][3]
     uint32_t *queue;              // work-item counter, zeroed before launch
+    unsigned long long endtimes_ref;   // -DRTW_ENDTIMES builds: reference wave lifetime for the histogram (0 = none)
     unsigned long long *stats;    // [0] camera rays [1] segments [2] sphere tests [3] node tests [4] nan pixels [5..7] phase steps [8..10] phase lanes [14] quad tests [16..19] steps, lanes of phases 3 (switch), 4 (new path)
 };
 

@@ -772,6 +772,11 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         // diagnostic build only: when do the waves of a launch start and finish?  (overwrites the census slots)
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         atomicMax(&A.stats[12], t_end - t_wave_start);     // longest wave lifetime (s_memtime is per XCD: only differences within a wave mean anything)
+        if (A.endtimes_ref) {                              // histogram of the lifetimes in 1/32 of a reference lifetime (a previous run's longest): stats[20 + 0..11] = the last 12 bins below / at it
+            const unsigned long long bin = (t_end - t_wave_start) * 32ull / A.endtimes_ref;
+            const unsigned long long b = bin >= 32ull ? 11ull : (bin >= 21ull ? bin - 21ull : 0ull);
+            atomicAdd(&A.stats[20 + b], 1ull);
+        }
         atomicAdd(&A.stats[13], t_end - t_wave_start);     // sum of the waves' lifetimes
         atomicAdd(&A.stats[15], 1ull);                     // waves
 #endif

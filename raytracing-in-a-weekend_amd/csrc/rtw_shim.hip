@@ -409,6 +409,9 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     a.mint = p->mint; a.maxt = p->maxt;
     std::memcpy(a.bg, c->bg, sizeof a.bg);
     a.queue = c->d_queue; a.stats = c->d_stats;
+#ifdef RTW_ENDTIMES
+    if (const char *e = getenv("RTW_ENDTIMES_REF")) a.endtimes_ref = std::strtoull(e, nullptr, 10);       // diagnostic build only
+#endif
 
     // Work units are (tile, chunk of samples, pixel): a pixel's samples are spread over ceil(n / chunk_len) units
     // so that no lane owns more than chunk_len sequential paths (the slowest PIXEL used to set a ~50 ms tail).
@@ -580,6 +583,11 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
         for (int k = 3; k < 5; k++) { stats->phase_steps[k] = h_stats[16 + 2 * (k - 3)]; stats->phase_lanes[k] = h_stats[17 + 2 * (k - 3)]; }
 #if defined(RTW_STAMP) || defined(RTW_ENDTIMES)     // diagnostic builds only (scripts/gpu_endtimes.py)
         if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu\n", h_stats[11], h_stats[12], h_stats[13]);
+        if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15] && getenv("RTW_ENDTIMES_REF")) {
+            std::fprintf(stderr, "rtw endtimes histogram (waves ending in each 1/32 of the reference lifetime, bins 21/32 .. 32/32+; bin 0 also holds everything earlier):");
+            for (int k = 0; k < 12; k++) std::fprintf(stderr, " %llu", h_stats[20 + k]);
+            std::fprintf(stderr, "\n");
+        }
         if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15]) {   // RTW_ENDTIMES build: [12] longest wave lifetime [13] sum of wave lifetimes [15] waves
             std::fprintf(stderr, "rtw endtimes: %llu waves, longest lifetime %llu ticks, mean lifetime %.1f %% of it\n", h_stats[15], h_stats[12],
                          100.0 * (double)h_stats[13] / (double)h_stats[15] / (double)h_stats[12]);
