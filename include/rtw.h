@@ -40,6 +40,7 @@ extern "C" {
 #define RTW_E_NOMEM        -4   /* host or device allocation failed                                  */
 #define RTW_E_UNSUPPORTED  -5   /* valid enum value that this build does not implement on the device */
 #define RTW_E_NO_SCENE     -6   /* rtw_ctx_render() before rtw_ctx_set_scene()                       */
+#define RTW_E_INTERNAL     -7   /* a render kernel gave up (safety valve of its persistent loop): the image is incomplete */
 
 /* ---- integrators: which `ray_color` closure the reference would have passed ----------------- */
 enum {

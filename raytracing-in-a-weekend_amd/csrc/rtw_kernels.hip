@@ -31,6 +31,10 @@
 #include "rtw_kernels.h"
 #include <type_traits>
 
+#ifndef RTW_MAX_TRIPS
+#define RTW_MAX_TRIPS 0x30000000u   /* loop trips after which a wave of a persistent kernel gives up (safety valve; ~6000x what the bench frame needs per wave) */
+#endif
+
 namespace rtw {
 
 // ================================================================================================
@@ -71,6 +75,9 @@ struct Reserve {                             // wave-uniform
     uint32_t i0, k0;                         // the block's tile: first column, first compact row
     uint32_t s0, s1;                         // the block's chunk: samples [s0, s1)
     uint32_t unit;                           // tile * n_chunks + chunk: the block's place in the sample bank
+#ifdef RTW_ENDTIMES
+    unsigned long long t_dry;                // diagnostic build: device-wide time at which this wave first found the queue empty (0: not yet)
+#endif
 };
 
 // Pull the next work item for the lanes with `need` set.  Must be called by all lanes of the wave
@@ -86,6 +93,9 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
         if ((threadIdx.x & 63u) == leader) base = atomicAdd(A.queue, 64u);
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
         rs.next = base < A.total_work ? base : A.total_work;      // total_work is a multiple of 64
+#ifdef RTW_ENDTIMES
+        if (!(base < A.total_work) && rs.t_dry == 0ull) rs.t_dry = wall_clock64();
+#endif
         rs.end = rs.next + (base < A.total_work ? 64u : 0u);
         // Work unit = (8x8 tile, chunk of chunk_len samples, pixel of the tile); the units of one tile are consecutive.  The
         // block's tile and chunk are the same for its 64 items: the three integer divisions run once per block, here.
@@ -384,12 +394,17 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 4 : 1) void render_brute(const KA
     bool dead = false, have = false, newpath = false;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
     Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = 0;
+#ifdef RTW_ENDTIMES
+    rs.t_dry = 0ull;
+#endif
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
     uint32_t n_seg = 0, n_rays = 0, n_isph = 0, n_quad = 0;
+    uint32_t trips = 0; bool aborted = false;
 
     for (;;) {
         if (fetch_pixel(A, !have && !dead, px, dead, rs)) { have = true; newpath = true; }
         if (__ballot(!dead) == 0ull) break;
+        if (++trips > RTW_MAX_TRIPS) { aborted = true; break; }       // safety valve, as in render_bvh
         if (have && newpath) { newpath = false; start_path<SPEC>(A, px, pt); n_rays++; }
         if (have) {
             bool finished;
@@ -409,6 +424,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 4 : 1) void render_brute(const KA
     }
     flush_counters(A, n_seg, n_rays, (unsigned long long)n_seg * A.sc.n + n_isph, 0);
     if (GEOM) flush_quads(A, n_quad);
+    if (aborted && (threadIdx.x & 63u) == 0) atomicAdd(&A.stats[23], 1ull);
 }
 
 // ================================================================================================
@@ -458,6 +474,10 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 #endif
 #ifndef RTW_T_LO
 #define RTW_T_LO 6u             /* below this many lanes in TRAVERSE and in LEAF, SHADE runs anyway */
+#endif
+#ifndef RTW_T_LO_DRAIN
+#define RTW_T_LO_DRAIN RTW_T_LO /* the same once the work queue is empty.  1 ("SHADE only when no lane traverses any more") was measured: the bench frame and C4
+                                   lose 0.6 %, C2 gains 1.6 %, `First frame` 5 %, an eighth of the bench frame nothing (profiles/r02_drain_ab.log) */
 #endif
 
 struct Trav {                // traversal state of one lane
@@ -663,6 +683,9 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     uint32_t fl = 0u;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
     Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = 0;
+#ifdef RTW_ENDTIMES
+    rs.t_dry = 0ull;
+#endif
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
     Trav tr; tr.node = (int)Code<stack_t>::END; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.selx = tr.sely = tr.selz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
@@ -670,6 +693,8 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     // lanes live in TRAVERSE steps, leaf tests == lanes live in LEAF steps), which keeps four VGPRs out of the loop.
     // (32-bit: one wave's share of a launch -- at most 2^32 sample slots per launch, rtw_ctx_render -- stays far below 2^32)
     uint32_t w_seg = 0, w_rays = 0;
+    uint32_t t_lo = RTW_T_LO;                       // wave-uniform: drops to RTW_T_LO_DRAIN once the queue is empty
+    uint32_t trips = 0; bool aborted = false;       // wave-uniform
     uint32_t n_isph = 0, n_quad = 0;                // GEOM builds only: member-sphere and quad tests of the extra stage
     uint32_t c_steps[3] = { 0, 0, 0 };              // wave-uniform (SGPR) census of the scheduler
     uint32_t c_lanes[3] = { 0, 0, 0 };
@@ -679,6 +704,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
 
 #ifdef RTW_ENDTIMES
     const unsigned long long t_wave_start = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt_wave_start = wall_clock64();     // s_memrealtime: one 100 MHz clock for the whole device (s_memtime is per XCD)
 #endif
     for (;;) {
         // ---- scheduler ---------------------------------------------------------------------------
@@ -689,7 +715,10 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         const uint32_t nL = lanes_in(in_leaf(tr.node));
         const uint32_t nS = lanes_in(in_shade<stack_t>(tr.node));
         if ((nT | nL | nS) == 0u) break;                     // every lane is DEAD
-        const bool run_shade = nS >= RTW_S_HI || (nT < RTW_T_LO && nL < RTW_T_LO && nS > 0u);
+        // Safety valve of the persistent loop: a wave that has taken an absurd number of scheduler trips (the bench frame needs ~130 k per
+        // wave) gives up instead of hanging the GPU; the launch then reports RTW_E_INTERNAL (stats[23] counts such waves).
+        if (++trips > RTW_MAX_TRIPS) { aborted = true; break; }
+        const bool run_shade = nS >= RTW_S_HI || (nT < t_lo && nL < t_lo && nS > 0u);
         const bool run_leaf = nL > nT;
 #ifdef RTW_STAMP
         const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -714,6 +743,11 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
             //    reserve must stay wave-uniform, which it only does if all lanes run its bookkeeping.
             bool exhausted = false;
             const bool got = fetch_pixel(A, need_unit, px, exhausted, rs);
+            // Once the queue is empty the wave only drains: its lanes die one by one, S_HI can no longer be reached and SHADE runs on the
+            // "few lanes traverse" rule alone -- after finding the queue empty a wave runs on for 0.38 ms on average and 1.2 ms at most
+            // (profiles/r02_endtimes.log).  The threshold of that rule can differ while draining (RTW_T_LO_DRAIN; measured, not better).
+            // (HERE, where every lane of the wave is active: t_lo steers the scheduler and must stay wave-uniform.)
+            if (__ballot(exhausted) != 0ull) t_lo = RTW_T_LO_DRAIN;
             if (shading) {
                 if (got) fl |= F_HAVE | F_NEWPATH;
                 if (exhausted) tr.node = (int)Code<stack_t>::DEAD;
@@ -765,6 +799,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         atomicAdd(&A.stats[2], (unsigned long long)c_lanes[1] + (unsigned long long)w_seg * A.bvh.n_big);   // leaf tests + the big-sphere pre-pass of every query
         atomicAdd(&A.stats[3], (unsigned long long)c_lanes[0]);
         for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[5 + k], (unsigned long long)c_steps[k]); atomicAdd(&A.stats[8 + k], (unsigned long long)c_lanes[k]); }
+        if (aborted) atomicAdd(&A.stats[23], 1ull);
 #ifdef RTW_STAMP
         for (int k = 0; k < 3; k++) atomicAdd(&A.stats[11 + k], c_time[k]);
 #endif
@@ -779,6 +814,12 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
         }
         atomicAdd(&A.stats[13], t_end - t_wave_start);     // sum of the waves' lifetimes
         atomicAdd(&A.stats[15], 1ull);                     // waves
+        const unsigned long long rt_end = wall_clock64();
+        atomicMin(&A.stats[24 + 8 - 8], rt_wave_start + 0ull);      // [24] earliest wave start   (device-wide 100 MHz ticks; [24], [26] are pre-set to ~0ull by the shim)
+        atomicMax(&A.stats[25], rt_wave_start);            // [25] latest wave start
+        atomicMin(&A.stats[26], rt_end);                   // [26] earliest wave end
+        atomicMax(&A.stats[27], rt_end);                   // [27] latest wave end
+        if (rs.t_dry) { atomicMin(&A.stats[28], rs.t_dry); atomicMax(&A.stats[29], rs.t_dry); atomicMax(&A.stats[30], rt_end - rs.t_dry); atomicAdd(&A.stats[31], rt_end - rs.t_dry); }
 #endif
     }
 }

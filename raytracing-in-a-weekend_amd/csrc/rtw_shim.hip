@@ -154,6 +154,7 @@ const char *rtw_strerror(int status) {
     case RTW_E_NOMEM: return "out of memory";
     case RTW_E_UNSUPPORTED: return "not implemented on the device";
     case RTW_E_NO_SCENE: return "no scene set";
+    case RTW_E_INTERNAL: return "a render kernel gave up (internal error): the image is incomplete";
     default: return "unknown status";
     }
 }
@@ -504,6 +505,11 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     }
 
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, RTW_N_STATS * sizeof(unsigned long long), c->stream));
+#ifdef RTW_ENDTIMES
+    HIP_TRY(hipMemsetAsync(c->d_stats + 24, 0xFF, sizeof(unsigned long long), c->stream));     // atomicMin targets (diagnostic build only)
+    HIP_TRY(hipMemsetAsync(c->d_stats + 26, 0xFF, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats + 28, 0xFF, sizeof(unsigned long long), c->stream));
+#endif
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (uint32_t tr0 = 0; tr0 < tile_rows || tr0 == 0; tr0 += (uint32_t)band_tile_rows) {
         const uint32_t tr1 = tr0 + (uint32_t)band_tile_rows < tile_rows ? tr0 + (uint32_t)band_tile_rows : tile_rows;
@@ -572,6 +578,7 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     const unsigned long long *h_stats = c->h_stats;
+    const bool kernel_gave_up = h_stats[23] != 0ull;           // safety valve of the persistent loop (rtw_kernels.hip RTW_MAX_TRIPS)
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->camera_rays = h_stats[0]; stats->segments = h_stats[1];
@@ -588,6 +595,12 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
             for (int k = 0; k < 12; k++) std::fprintf(stderr, " %llu", h_stats[20 + k]);
             std::fprintf(stderr, "\n");
         }
+        if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15])
+            std::fprintf(stderr, "rtw endtimes (100 MHz device clock): wave starts spread over %.1f us, first wave end %.1f us and last wave end %.1f us after the first start\n",
+                         (double)(h_stats[25] - h_stats[24]) / 100.0, (double)(h_stats[26] - h_stats[24]) / 100.0, (double)(h_stats[27] - h_stats[24]) / 100.0);
+        if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15])
+            std::fprintf(stderr, "rtw endtimes: the queue ran dry for the first wave %.1f us and for the last wave %.1f us after the first start; a wave then ran on for %.1f us on average, %.1f us at most\n",
+                         (double)(h_stats[28] - h_stats[24]) / 100.0, (double)(h_stats[29] - h_stats[24]) / 100.0, (double)h_stats[31] / (double)h_stats[15] / 100.0, (double)h_stats[30] / 100.0);
         if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15]) {   // RTW_ENDTIMES build: [12] longest wave lifetime [13] sum of wave lifetimes [15] waves
             std::fprintf(stderr, "rtw endtimes: %llu waves, longest lifetime %llu ticks, mean lifetime %.1f %% of it\n", h_stats[15], h_stats[12],
                          100.0 * (double)h_stats[13] / (double)h_stats[15] / (double)h_stats[12]);
@@ -595,7 +608,7 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
 #endif
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->pend.t0).count();
     }
-    return RTW_OK;
+    return kernel_gave_up ? RTW_E_INTERNAL : RTW_OK;
 }
 
 struct rtw_mgpu {
