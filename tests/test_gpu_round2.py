@@ -364,3 +364,15 @@ def test_bench_single_process_multi_gpu_path(gpu):
     assert d["n_gpus"] == 3 and d["value"] > 0 and "rtw_mgpu" in d["config"]["workload"]
     # three contexts traced the whole frame between them: 1920 x 1080 x 8 camera rays
     assert abs(d["roofline"]["units_per_launch"]["segments"] * 3 / (1920 * 1080 * 8) - d["config"]["segments_per_camera_ray"]) < 1e-3
+
+
+def test_persistent_loop_safety_valve(tmp_path):
+    """A wave of a persistent kernel that exceeds RTW_MAX_TRIPS scheduler trips gives up and the render returns RTW_E_INTERNAL (-7)
+    instead of hanging the GPU: a variant build with a limit of 1000 trips (the C2 frame needs far more) must come back with -7."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = str(tmp_path / "librtw_valve.so")
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "raytracing-in-a-weekend_amd", "csrc"), "OUT=" + lib, "EXTRA=-DRTW_MAX_TRIPS=1000u"], check=True, capture_output=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_valve_check.py")], env=dict(os.environ, RTW_HIP_LIB=lib), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "accel 1 -> -7" in out.stdout, out.stdout
