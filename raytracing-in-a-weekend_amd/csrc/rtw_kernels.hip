@@ -389,8 +389,11 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
     for (; s < n; ++s) test(geom[s], MOVING ? vel[s] : zero, s);
 }
 
+#ifndef RTW_GEOM_BRUTE_WAVES
+#define RTW_GEOM_BRUTE_WAVES 4        /* waves per SIMD the GEOM list-walk build is compiled for: presentation_image 3 / 4 / 5 / 6 = 213 / 188 / 186 / 228 ms (profiles/r02_geom_waves.log) */
+#endif
 template <bool MOVING, int SPEC, bool GEOM>
-__global__ __launch_bounds__(RTW_BLOCK, GEOM ? 4 : 1) void render_brute(const KArgs A) {
+__global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_GEOM_BRUTE_WAVES : 1) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
     Reserve rs; rs.next = rs.end = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = 0;
