@@ -49,8 +49,9 @@ struct KArgs {
     uint32_t s_root;              // strata per axis (STRATIFIED / CENTRES)
     uint32_t sampler, integrator, depth;
     uint32_t has_textures;        // any sphere with an image texture (selects the generic kernel)
-    uint32_t lds_bytes;           // dynamic LDS of the BVH kernel: stack | f16 nodes | sphere geometry
-    uint32_t lds_nodes_off, lds_geom_off;   // byte offsets (16-aligned); geom_off == 0: geometry stays in global memory
+    uint32_t lds_bytes;           // dynamic LDS of the BVH kernel: f16 nodes | stack | sphere geometry
+    uint32_t lds_stack_off, lds_geom_off;   // byte offsets (16-aligned) of the per-lane stack and of the sphere geometry (0: geometry stays in
+                                            // global memory); the f16 nodes sit at offset 0
     uint32_t seed_lo, seed_hi;
     float inv_gamma, mint, maxt;
     float bg[3];

@@ -665,8 +665,8 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     // {centre, r^2} of every sphere for the leaf tests.  Book-1: 6 KB + 15.5 KB (+ 7.8 KB).
     typedef typename std::conditional<LDSN, short, int>::type stack_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    *(stack_t *)(lds_raw + threadIdx.x * (uint32_t)sizeof(stack_t)) = (stack_t)Code<stack_t>::END;   // level 0: the sentinel (own slot, no sync needed)
-    u4 *lnodes = (u4 *)(lds_raw + A.lds_nodes_off);
+    *(stack_t *)(lds_raw + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t)) = (stack_t)Code<stack_t>::END;   // level 0: the sentinel (own slot, no sync needed)
+    u4 *lnodes = (u4 *)lds_raw;                     // offset 0 (rtw_shim.hip: the node fetch needs no base register)
     f4 *lgeom = (f4 *)(lds_raw + A.lds_geom_off);
     const bool geom_in_lds = LDSN && A.lds_geom_off != 0u;
     const DevScene &sc = A.sc;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
                         pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
                         fl |= F_DONE;                                      // banked on the next SHADE trip
                     } else {
-                        trav_begin<MOVING, stack_t>(A, pt, tr, lds_addr(lds_raw) + threadIdx.x * (uint32_t)sizeof(stack_t));
+                        trav_begin<MOVING, stack_t>(A, pt, tr, lds_addr(lds_raw) + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t));
                         fl |= F_INFLIGHT;
                     }
                 }

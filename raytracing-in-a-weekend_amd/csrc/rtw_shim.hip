@@ -481,10 +481,15 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         const bool ldsn = a.bvh.nodes16 != nullptr;
         // sentinel + one entry per tree level + the slot above the top the descend step always writes
         uint32_t levels = c->bvh.depth + 3; if (levels < 4) levels = 4;
-        uint32_t off = levels * RTW_BLOCK * (ldsn ? 2u : 4u);
+        // Layout: f16 nodes FIRST (LDS offset 0: the hottest address of the kernel, the node fetch of every visit, then needs no base
+        // register -- as the second block its offset was an SGPR the allocator spilled, one v_readlane per visit), then the per-lane
+        // stack, then the optional sphere geometry.
+        uint32_t off = 0;
+        if (ldsn) { off = c->bvh.n_nodes * 32u; off = (off + 15u) & ~15u; }
+        a.lds_stack_off = off;
+        off += levels * RTW_BLOCK * (ldsn ? 2u : 4u);
         off = (off + 15u) & ~15u;
         if (ldsn) {
-            a.lds_nodes_off = off; off += c->bvh.n_nodes * 32u; off = (off + 15u) & ~15u;
             // sphere geometry rides along only while the workgroup stays under 1/6 of the CU's 160 KiB, i.e. while
             // it does not cost a resident workgroup at the kernel's register budget (6 waves/SIMD)
             bool geom = off + c->sc.n * 16u <= 160u * 1024u / 6u;
