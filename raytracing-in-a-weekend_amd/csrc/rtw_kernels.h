@@ -65,6 +65,8 @@ struct KArgs {
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream);
 // Resident workgroups per CU for the kernel variant (occupancy API), >= 1.
 uint32_t kernel_blocks_per_cu(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes);
+// Is there a build of the BVH kernel for this configuration that reads the spheres' {centre, r^2} from LDS?  (KArgs.lds_geom_off may only be set then)
+bool kernel_has_lds_geom(const KArgs &a);
 // The kernel variant launch_render would pick, as an opaque id (key of the per-context occupancy cache).
 const void *kernel_id(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes);
 

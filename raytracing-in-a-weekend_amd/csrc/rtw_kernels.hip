@@ -601,8 +601,20 @@ __device__ __forceinline__ void trav_descend(Trav &tr, float e0, float x0, float
     const bool both = h0 && h1, none = !(h0 || h1);
     const bool near0 = h0 && (!h1 || le);
     const uint32_t level = RTW_BLOCK * (uint32_t)sizeof(S);
-    lds_put<S>(tr.sp + level, (S)(near0 ? c1 : c0));
-    tr.node = entry_to_node<S>(none ? popped : (near0 ? c0 : c1));
+    if (sizeof(S) == 2) {
+        // c0 holds {c0, c1} as halves: rotate the nearer child into the low half (one select of the rotate amount + v_alignbit), the
+        // farther one is then stored straight from the high half (ds_write_b16_d16_hi) -- 2 VALU for near AND far instead of 3.
+        // The condition is built as ONE lane mask from the three compares' ballots (scalar unit): left to the selector,
+        // select(a && b, ..) becomes two nested v_cndmask.
+        const uint64_t H0 = __builtin_amdgcn_ballot_w64(h0), H1 = __builtin_amdgcn_ballot_w64(h1), LE = __builtin_amdgcn_ballot_w64(le);
+        const bool far0 = __builtin_amdgcn_inverse_ballot_w64(~H0 | (H1 & ~LE));
+        const uint32_t nf = __builtin_amdgcn_alignbit(c0, c0, far0 ? 16u : 0u);
+        lds_put<unsigned short>(tr.sp + level, (unsigned short)(nf >> 16));
+        tr.node = entry_to_node<S>(none ? popped : nf);
+    } else {
+        lds_put<S>(tr.sp + level, (S)(near0 ? c1 : c0));
+        tr.node = entry_to_node<S>(none ? popped : (near0 ? c0 : c1));
+    }
     tr.sp = (tr.sp + (both ? level : 0u)) - (none ? level : 0u);
 }
 
@@ -620,7 +632,7 @@ __device__ __forceinline__ void trav_node_lds(const u4 *lnodes, Trav &tr) {
     const u4 r0 = lnodes[tr.node * 2];
     const u3 r1 = *(const u3 *)(lnodes + tr.node * 2 + 1);     // 12 of the 16 bytes: no dead destination register for the allocator to recycle early
     // r0 = box0 {lo hi}.x  box0 {lo hi}.y  box0 {lo hi}.z  box1 {lo hi}.x      r1 = box1 {lo hi}.y  box1 {lo hi}.z  {c0 c1}
-    const uint32_t c0 = r1.z, c1 = r1.z >> 16;
+    const uint32_t c0 = r1.z, c1 = 0;             // both ids in one dword (trav_descend<short> rotates it)
     // {near plane, far plane} of each (box, axis): the halves as stored or swapped, by the ray's direction along the axis
     const uint32_t ax = __builtin_amdgcn_perm(r0.x, r0.x, tr.selx), ay = __builtin_amdgcn_perm(r0.y, r0.y, tr.sely), az = __builtin_amdgcn_perm(r0.z, r0.z, tr.selz);
     const uint32_t bx = __builtin_amdgcn_perm(r0.w, r0.w, tr.selx), by = __builtin_amdgcn_perm(r1.x, r1.x, tr.sely), bz = __builtin_amdgcn_perm(r1.y, r1.y, tr.selz);
@@ -657,8 +669,11 @@ __device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr) {
 #ifndef RTW_BVH_WAVES
 #define RTW_BVH_WAVES 4        /* min waves per SIMD the register allocator must leave room for */
 #endif
-template <bool MOVING, bool LDSN, int SPEC, bool GEOM>
+// NODES: 0 = f32 nodes in global memory, 32-bit stack; 1 = f16 nodes in LDS, 16-bit stack; 2 = as 1, and the spheres' {centre, r^2} in LDS
+// too (a build of its own: as a run-time choice the leaf test went through a flat load and a select of two addresses, 7 VALU).
+template <bool MOVING, int NODES, int SPEC, bool GEOM>
 __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bvh(const KArgs A) {
+    constexpr bool LDSN = NODES != 0, geom_in_lds = NODES == 2;
     // LDS is all dynamic, sized by the host for THIS tree (rtw_ctx_render): the per-lane traversal stack
     // [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel, one per tree level, and the slot
     // above the top that the select-form descend always writes; 16-bit entries in the LDS-node variant), then -- LDS-node variant -- the f16 nodes and, when it does not cost a resident workgroup,
@@ -668,7 +683,6 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bv
     *(stack_t *)(lds_raw + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t)) = (stack_t)Code<stack_t>::END;   // level 0: the sentinel (own slot, no sync needed)
     u4 *lnodes = (u4 *)lds_raw;                     // offset 0 (rtw_shim.hip: the node fetch needs no base register)
     f4 *lgeom = (f4 *)(lds_raw + A.lds_geom_off);
-    const bool geom_in_lds = LDSN && A.lds_geom_off != 0u;
     const DevScene &sc = A.sc;
     if (LDSN) {
         const u4 *src = (const u4 *)A.bvh.nodes16;
@@ -836,27 +850,31 @@ static bool is_common_config(const KArgs &a) {
            (a.flags & (RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE)) == 0u;
 }
 template <int SPEC>
-static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, bool lds_nodes) {
+static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, int nodes) {
     if (accel == RTW_ACCEL_BVH) {
-        if (lds_nodes) return moving ? render_bvh<true, true, SPEC, false> : render_bvh<false, true, SPEC, false>;
-        return moving ? render_bvh<true, false, SPEC, false> : render_bvh<false, false, SPEC, false>;
+        if (nodes == 2) return moving ? render_bvh<true, 2, SPEC, false> : render_bvh<false, 2, SPEC, false>;
+        if (nodes == 1) return moving ? render_bvh<true, 1, SPEC, false> : render_bvh<false, 1, SPEC, false>;
+        return moving ? render_bvh<true, 0, SPEC, false> : render_bvh<false, 0, SPEC, false>;
     }
     return moving ? render_brute<true, SPEC, false> : render_brute<false, SPEC, false>;
 }
-// quads / instances in the scene: the generic build with the extra closest-hit stage
-static kernel_fn pick_kernel_geom(bool moving, uint32_t accel, bool lds_nodes) {
+// quads / instances in the scene: the generic build with the extra closest-hit stage (sphere geometry always global: kernel_has_lds_geom)
+static kernel_fn pick_kernel_geom(bool moving, uint32_t accel, int nodes) {
     if (accel == RTW_ACCEL_BVH) {
-        if (lds_nodes) return moving ? render_bvh<true, true, 0, true> : render_bvh<false, true, 0, true>;
-        return moving ? render_bvh<true, false, 0, true> : render_bvh<false, false, 0, true>;
+        if (nodes) return moving ? render_bvh<true, 1, 0, true> : render_bvh<false, 1, 0, true>;
+        return moving ? render_bvh<true, 0, 0, true> : render_bvh<false, 0, 0, true>;
     }
     return moving ? render_brute<true, 0, true> : render_brute<false, 0, true>;
 }
 static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes) {
-    if (a.geom.n_quads || a.geom.n_inst) return pick_kernel_geom(moving, accel, lds_nodes);
-    if (!is_common_config(a)) return pick_kernel_spec<0>(moving, accel, lds_nodes);
-    if (a.flags & RTW_FLAG_CHUNK_SUMS) return a.has_textures ? pick_kernel_spec<0>(moving, accel, lds_nodes) : pick_kernel_spec<3>(moving, accel, lds_nodes);
-    return a.has_textures ? pick_kernel_spec<2>(moving, accel, lds_nodes) : pick_kernel_spec<1>(moving, accel, lds_nodes);
+    const int nodes = lds_nodes ? (a.lds_geom_off ? 2 : 1) : 0;
+    if (a.geom.n_quads || a.geom.n_inst) return pick_kernel_geom(moving, accel, nodes);
+    if (!is_common_config(a)) return pick_kernel_spec<0>(moving, accel, nodes);
+    if (a.flags & RTW_FLAG_CHUNK_SUMS) return a.has_textures ? pick_kernel_spec<0>(moving, accel, nodes) : pick_kernel_spec<3>(moving, accel, nodes);
+    return a.has_textures ? pick_kernel_spec<2>(moving, accel, nodes) : pick_kernel_spec<1>(moving, accel, nodes);
 }
+
+bool kernel_has_lds_geom(const KArgs &a) { return !(a.geom.n_quads || a.geom.n_inst); }
 
 void launch_render(const KArgs &a, bool moving, uint32_t accel, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(pick_kernel(a, moving, accel, a.bvh.nodes16 != nullptr), dim3(grid), dim3(RTW_BLOCK), a.lds_bytes, stream, a);

@@ -494,7 +494,7 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
             // it does not cost a resident workgroup at the kernel's register budget (6 waves/SIMD)
             bool geom = off + c->sc.n * 16u <= 160u * 1024u / 6u;
             if (c->opt_lds_geom >= 0) geom = c->opt_lds_geom != 0 && c->sc.n <= RTW_LDS_GEOM_MAX;
-            if (geom) { a.lds_geom_off = off; off += c->sc.n * 16u; }
+            if (geom && kernel_has_lds_geom(a)) { a.lds_geom_off = off; off += c->sc.n * 16u; }
         }
         a.lds_bytes = off;
     }
