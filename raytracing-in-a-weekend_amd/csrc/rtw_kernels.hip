@@ -669,10 +669,13 @@ __device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr) {
 #ifndef RTW_BVH_WAVES
 #define RTW_BVH_WAVES 4        /* min waves per SIMD the register allocator must leave room for */
 #endif
+#ifndef RTW_BVH_WAVES_TEX
+#define RTW_BVH_WAVES_TEX 6
+#endif
 // NODES: 0 = f32 nodes in global memory, 32-bit stack; 1 = f16 nodes in LDS, 16-bit stack; 2 = as 1, and the spheres' {centre, r^2} in LDS
 // too (a build of its own: as a run-time choice the leaf test went through a flat load and a select of two addresses, 7 VALU).
 template <bool MOVING, int NODES, int SPEC, bool GEOM>
-__global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : RTW_BVH_WAVES) void render_bvh(const KArgs A) {
+__global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : (SPEC == 2 ? RTW_BVH_WAVES_TEX : RTW_BVH_WAVES)) void render_bvh(const KArgs A) {
     constexpr bool LDSN = NODES != 0, geom_in_lds = NODES == 2;
     // LDS is all dynamic, sized by the host for THIS tree (rtw_ctx_render): the per-lane traversal stack
     // [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel, one per tree level, and the slot
