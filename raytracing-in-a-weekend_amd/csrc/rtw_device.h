@@ -72,6 +72,27 @@ __device__ __forceinline__ float div_plain(float n, float d, float r) {
     q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
     return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
 }
+// The accepted root of a sphere test, `(-b - sqrt(disc)) / a`, or `(-b + sqrt(disc)) / a` when that one lies before mint (sphere.rs:106-116),
+// for lanes with disc >= 0 (the caller's exec mask).  `ra` = rcp_refined(a); `a_plain` (wave-uniform) says every lane's a is in
+// [2^-20, 2^20].  With disc in [2^-60, 2^96] in every active lane as well, the plain sequences give the bits of the generic expansions:
+// sqrt(disc) >= 2^-30 makes each numerator either 0 (quotient +-0 either way: below mint, never stored) or >= 2^-54 in magnitude (it is the
+// rounded sum of two floats of which one is >= 2^-30), so no residual of div_plain can leave the normal range (they are multiples of
+// ulp(a) * ulp(q) >= 2^-43 * 2^-98); disc <= 2^96 also bounds |b| < 2^64 (b * b would have overflowed), so no quotient overflows.
+// One integer range compare and one ballot per test; any other lane (disc = -0, a denormal, inf, NaN) sends the wave down the generic code.
+__device__ __forceinline__ float sphere_root(float b, float disc, float a, float ra, bool a_plain, float mint) {
+    const bool plain = (__float_as_uint(disc) - 0x21800000u) <= (0x6F800000u - 0x21800000u);      // 2^-60 <= disc <= 2^96
+    float x;
+    if (a_plain && __ballot(!plain) == 0ull) {
+        const float sq = sqrt_plain(disc);
+        x = div_plain(-b - sq, a, ra);
+        if (x < mint) x = div_plain(-b + sq, a, ra);
+    } else {
+        const float sq = __builtin_sqrtf(disc);
+        x = (-b - sq) / a;
+        if (x < mint) x = (-b + sq) / a;
+    }
+    return x;
+}
 __device__ __forceinline__ bool in_range(float v, float lo, float hi) { const float a = __builtin_fabsf(v); return a >= lo && a <= hi; }
 
 // unit(a) = a / sqrt(a.a) (vec3.rs:213), correctly rounded sqrt and divisions.  hipcc expands every IEEE f32 sqrt to 17 and every

@@ -351,6 +351,8 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
     cf4_ptr geom = (cf4_ptr)(uintptr_t)sc.geom;
     cf4_ptr vel = (cf4_ptr)(uintptr_t)sc.vel;
     const float a = dot(d, d);
+    const float ra = rcp_refined(a);
+    const bool a_plain = __ballot(!in_range(a, 0x1p-20f, 0x1p20f)) == 0ull;      // see sphere_root()
     best = -1; best_t = 0.0f;
     const uint32_t n = sc.n;
     auto test = [&](f4 g, f4 vv, uint32_t s) {
@@ -361,9 +363,7 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
         float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
         float disc = b * b - a * c;
         if (!(disc < 0.0f)) {
-            float sq = __builtin_sqrtf(disc);
-            float x = (-b - sq) / a;
-            if (x < mint) x = (-b + sq) / a;
+            const float x = sphere_root(b, disc, a, ra, a_plain, mint);
             if (!(x < mint || x > maxt)) {
                 if (best < 0 || best_t > x) { best = (int)s; best_t = x; }
             }
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_GEOM_BRUTE_WAVES : 1) void re
 // order here, so ties are resolved explicitly toward the lower index -- the sphere `min_hit > i`
 // keeps in list order.
 template <bool MOVING>
-__device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d, float tm, float a, float mint, float maxt,
+__device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d, float tm, float a, float ra, bool a_plain, float mint, float maxt,
                                              int &best, float &best_t) {
     float cx = g.x, cy = g.y, cz = g.z;
     if (MOVING) { cx = cx + vv.x * tm; cy = cy + vv.y * tm; cz = cz + vv.z * tm; }
@@ -447,9 +447,7 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
     float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
     float disc = b * b - a * c;
     if (!(disc < 0.0f)) {
-        float sq = __builtin_sqrtf(disc);
-        float x = (-b - sq) / a;
-        if (x < mint) x = (-b + sq) / a;
+        const float x = sphere_root(b, disc, a, ra, a_plain, mint);
         if (!(x < mint || x > maxt)) {
             if (x < best_t || (x == best_t && s < (uint32_t)best)) { best = (int)s; best_t = x; }
         }
@@ -489,7 +487,7 @@ struct Trav {                // traversal state of one lane
     uint32_t sp;             // LDS byte ADDRESS of the TOP entry of this lane's stack, base + (level * RTW_BLOCK + threadIdx.x) * sizeof(entry);
                              // level 0 holds the END sentinel, so a pop never has to ask whether the stack is empty
     int best; float best_t;  // closest accepted hit so far (best_t starts at maxt)
-    float a;                 // d.d
+    float a, ra;             // d.d and rcp_refined(d.d) (sphere_root)
     float ix, iy, iz;        // 1/d
     float kpx, kpy, kpz;     // global-node variant: -(o + rho) / d (goes with a box's lo planes); LDS variant: the NEAR planes' constant
     float kmx, kmy, kmz;     // global-node variant: -(o - rho) / d (hi planes);                    LDS variant: the FAR planes' constant
@@ -515,17 +513,20 @@ __device__ __forceinline__ uint32_t lanes_in(bool c) {
 
 // Begin a closest-hit query: big spheres, per-ray constants, root (which sets the phase).
 template <bool MOVING, class S>
-__device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav &tr, uint32_t sp0) {
+__device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav &tr, uint32_t sp0, bool a_plain_wave, bool &a_odd) {
     const DevBvh &bv = A.bvh;
     const v3 o = pt.o, d = pt.d;
     tr.a = dot(d, d);
+    tr.ra = rcp_refined(tr.a);
+    a_odd = !in_range(tr.a, 0x1p-20f, 0x1p20f);           // (per lane; the caller folds it into the wave's sticky flag where the wave is whole)
+    const bool a_plain = a_plain_wave && __ballot(a_odd) == 0ull;
     tr.best = -1; tr.best_t = A.maxt; tr.sp = sp0;           // the lane's level-0 slot (the sentinel)
     {   // big spheres: uniform loop, scalar loads
         cf4_ptr bg = (cf4_ptr)(uintptr_t)bv.big_geom;
         cf4_ptr bvel = (cf4_ptr)(uintptr_t)bv.big_vel;
         for (uint32_t k = 0; k < bv.n_big; ++k) {
             f4 vv = MOVING ? bvel[k] : f4{ 0, 0, 0, 0 };
-            exact_sphere<MOVING>(bg[k], vv, bv.big_index[k], o, d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
+            exact_sphere<MOVING>(bg[k], vv, bv.big_index[k], o, d, pt.tm, tr.a, tr.ra, a_plain, A.mint, A.maxt, tr.best, tr.best_t);
         }
     }
     tr.node = bv.root;
@@ -620,6 +621,7 @@ __device__ __forceinline__ void trav_descend(Trav &tr, float e0, float x0, float
 
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32a2 __attribute__((aligned(2)));
 // f16 halves of a dword as f32 (scalar casts only: element access through f16 ext-vectors is miscompiled
 // by this toolchain -- lanes came back undefined)
 __device__ __forceinline__ float h_lo(unsigned int w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)); }
@@ -631,6 +633,13 @@ __device__ __forceinline__ void trav_node_lds(const u4 *lnodes, Trav &tr) {
     const uint32_t popped = lds_get<unsigned short>(tr.sp);
     const u4 r0 = lnodes[tr.node * 2];
     const u3 r1 = *(const u3 *)(lnodes + tr.node * 2 + 1);     // 12 of the 16 bytes: no dead destination register for the allocator to recycle early
+#ifdef RTW_LDS_PROBE
+    {   // experiment: how much LDS headroom is there?  RTW_LDS_PROBE extra (2-byte-aligned) dword reads per visit, results only consumed
+        const uint32_t pa = (uint32_t)tr.node * 32u + ((tr.selx & 1u) << RTW_LDS_PROBE_SH);
+        #pragma unroll
+        for (int k = 0; k < RTW_LDS_PROBE; k++) { const uint32_t x = lds_get<u32a2>(pa + 4u * k); asm volatile("" :: "v"(x)); }
+    }
+#endif
     // r0 = box0 {lo hi}.x  box0 {lo hi}.y  box0 {lo hi}.z  box1 {lo hi}.x      r1 = box1 {lo hi}.y  box1 {lo hi}.z  {c0 c1}
     const uint32_t c0 = r1.z, c1 = 0;             // both ids in one dword (trav_descend<short> rotates it)
     // {near plane, far plane} of each (box, axis): the halves as stored or swapped, by the ray's direction along the axis
@@ -666,16 +675,25 @@ __device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr) {
     trav_descend<int>(tr, e0, x0, e1, x1, c0, c1, popped);
 }
 
+#ifdef RTW_STAMP
+// diagnostic build: wave-ticks (s_memtime) of the sub-steps of SHADE, summed into sub[k]
+#define RTW_SUB_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_now = __builtin_amdgcn_s_memtime(); sub[k] += t_now - t_sub; t_sub = t_now; } while (0)
+#else
+#define RTW_SUB_STAMP(k) do { } while (0)
+#endif
 #ifndef RTW_BVH_WAVES
 #define RTW_BVH_WAVES 4        /* min waves per SIMD the register allocator must leave room for */
 #endif
-#ifndef RTW_BVH_WAVES_TEX
-#define RTW_BVH_WAVES_TEX 6
+#ifndef RTW_BVH_WAVES_GEOM
+#define RTW_BVH_WAVES_GEOM 2   /* 4 (128 VGPRs, 26 dwords of scratch) measured: no gain */
+#endif
+#ifndef RTW_BVH_WAVES_SPEC
+#define RTW_BVH_WAVES_SPEC 6
 #endif
 // NODES: 0 = f32 nodes in global memory, 32-bit stack; 1 = f16 nodes in LDS, 16-bit stack; 2 = as 1, and the spheres' {centre, r^2} in LDS
 // too (a build of its own: as a run-time choice the leaf test went through a flat load and a select of two addresses, 7 VALU).
 template <bool MOVING, int NODES, int SPEC, bool GEOM>
-__global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : (SPEC == 2 ? RTW_BVH_WAVES_TEX : RTW_BVH_WAVES)) void render_bvh(const KArgs A) {
+__global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ? RTW_BVH_WAVES_SPEC : RTW_BVH_WAVES)) void render_bvh(const KArgs A) {
     constexpr bool LDSN = NODES != 0, geom_in_lds = NODES == 2;
     // LDS is all dynamic, sized by the host for THIS tree (rtw_ctx_render): the per-lane traversal stack
     // [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel, one per tree level, and the slot
@@ -707,7 +725,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : (SPEC == 2 ? RTW_BVH_WAVES_TE
     rs.t_dry = 0ull;
 #endif
     Path pt; pt.o = pt.d = pt.L = mk(0, 0, 0); pt.thr = mk(1, 1, 1); pt.tm = 0; pt.k = 0; pt.poison = false; pt.rng.state = 0; pt.rng.inc = 1;
-    Trav tr; tr.node = (int)Code<stack_t>::END; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = 1; tr.ix = tr.iy = tr.iz = 0;
+    Trav tr; tr.node = (int)Code<stack_t>::END; tr.sp = 0; tr.best = -1; tr.best_t = 0; tr.a = tr.ra = 1; tr.ix = tr.iy = tr.iz = 0;
     tr.kpx = tr.kpy = tr.kpz = tr.kmx = tr.kmy = tr.kmz = 0; tr.selx = tr.sely = tr.selz = 0; tr.tau_t = tr.lo_lim = tr.hi_lim = 0;
     // Work counters live in SGPRs: they are sums of ballot popcounts the scheduler computes anyway (node visits ==
     // lanes live in TRAVERSE steps, leaf tests == lanes live in LEAF steps), which keeps four VGPRs out of the loop.
@@ -715,11 +733,13 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : (SPEC == 2 ? RTW_BVH_WAVES_TE
     uint32_t w_seg = 0, w_rays = 0;
     uint32_t t_lo = RTW_T_LO;                       // wave-uniform: drops to RTW_T_LO_DRAIN once the queue is empty
     uint32_t trips = 0; bool aborted = false;       // wave-uniform
+    bool a_plain = true;                            // wave-uniform, sticky (trav_begin)
     uint32_t n_isph = 0, n_quad = 0;                // GEOM builds only: member-sphere and quad tests of the extra stage
     uint32_t c_steps[3] = { 0, 0, 0 };              // wave-uniform (SGPR) census of the scheduler
     uint32_t c_lanes[3] = { 0, 0, 0 };
 #ifdef RTW_STAMP
     unsigned long long c_time[3] = { 0, 0, 0 };
+    unsigned long long sub[5] = { 0, 0, 0, 0, 0 }, t_sub = 0;     // SHADE: hit / bank + next unit / camera ray / query begin / rest
 #endif
 
 #ifdef RTW_ENDTIMES
@@ -747,15 +767,21 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : (SPEC == 2 ? RTW_BVH_WAVES_TE
         if (run_shade) {
             c_steps[2]++; c_lanes[2] += nS;
             // a. the closest-hit query this lane was waiting on is complete: scatter, or end the path
-            bool need_unit = false, started = false;
+            bool need_unit = false, started = false, a_odd = false;
             const bool shading = in_shade<stack_t>(tr.node);
             w_seg += (uint32_t)__popcll(__ballot(shading && (fl & F_INFLIGHT) != 0u));
+#ifdef RTW_STAMP
+            t_sub = t_begin;
+#endif
             if (shading) {
                 if (fl & F_INFLIGHT) {
                     fl &= ~F_INFLIGHT;
                     const bool done = GEOM ? shade_geom<MOVING>(A, pt, tr.best, tr.best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t);
                     if (done) fl |= F_DONE;
                 }
+            }
+            RTW_SUB_STAMP(0);
+            if (shading) {
                 if (fl & F_DONE) { fl &= ~F_DONE; if (finish_path<SPEC>(A, px, pt)) fl &= ~F_HAVE; else fl |= F_NEWPATH; }
                 need_unit = (fl & F_HAVE) == 0u;
             }
@@ -768,6 +794,15 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : (SPEC == 2 ? RTW_BVH_WAVES_TE
             // (profiles/r02_endtimes.log).  The threshold of that rule can differ while draining (RTW_T_LO_DRAIN; measured, not better).
             // (HERE, where every lane of the wave is active: t_lo steers the scheduler and must stay wave-uniform.)
             if (__ballot(exhausted) != 0ull) t_lo = RTW_T_LO_DRAIN;
+            RTW_SUB_STAMP(1);
+#ifdef RTW_STAMP
+            if (shading) {
+                if (got) fl |= F_HAVE | F_NEWPATH;
+                if (exhausted) tr.node = (int)Code<stack_t>::DEAD;
+                if ((fl & F_HAVE) && (fl & F_NEWPATH)) { fl &= ~F_NEWPATH; start_path<SPEC>(A, px, pt); started = true; }
+            }
+            RTW_SUB_STAMP(2);
+#endif
             if (shading) {
                 if (got) fl |= F_HAVE | F_NEWPATH;
                 if (exhausted) tr.node = (int)Code<stack_t>::DEAD;
@@ -779,12 +814,16 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : (SPEC == 2 ? RTW_BVH_WAVES_TE
                         pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
                         fl |= F_DONE;                                      // banked on the next SHADE trip
                     } else {
-                        trav_begin<MOVING, stack_t>(A, pt, tr, lds_addr(lds_raw) + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t));
+                        trav_begin<MOVING, stack_t>(A, pt, tr, lds_addr(lds_raw) + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t), a_plain, a_odd);
                         fl |= F_INFLIGHT;
                     }
                 }
             }
+            RTW_SUB_STAMP(3);
             w_rays += (uint32_t)__popcll(__ballot(started));
+            // Wave-uniform and STICKY: lanes of this wave still test leaves of queries begun in earlier SHADE steps, so once any lane's d.d
+            // has left [2^-20, 2^20] the wave stays on the generic sqrt / division (same bits, a few more instructions) for good.
+            if (__ballot(a_odd) != 0ull) a_plain = false;
         } else if (!run_leaf) {
             // RTW_TRAV_UNROLL node visits per scheduling decision: the scheduler's ballots and branches are
             // paid once per burst; lanes that leave TRAVERSE (leaf reached / query done) sit out the rest of it.
@@ -801,7 +840,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : (SPEC == 2 ? RTW_BVH_WAVES_TE
             if (in_leaf(tr.node)) {
                 const uint32_t s = (uint32_t)~tr.node;
                 const f4 gs = geom_in_lds ? lgeom[s] : sc.geom[s];
-                exact_sphere<MOVING>(gs, MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, A.mint, A.maxt, tr.best, tr.best_t);
+                exact_sphere<MOVING>(gs, MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, tr.ra, a_plain, A.mint, A.maxt, tr.best, tr.best_t);
                 tr.hi_lim = tr.best_t + tr.tau_t;
                 trav_pop<stack_t>(tr);
             }
@@ -822,6 +861,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? 2 : (SPEC == 2 ? RTW_BVH_WAVES_TE
         if (aborted) atomicAdd(&A.stats[23], 1ull);
 #ifdef RTW_STAMP
         for (int k = 0; k < 3; k++) atomicAdd(&A.stats[11 + k], c_time[k]);
+        for (int k = 0; k < 4; k++) atomicAdd(&A.stats[16 + k], sub[k]);
 #endif
 #ifdef RTW_ENDTIMES
         // diagnostic build only: when do the waves of a launch start and finish?  (overwrites the census slots)

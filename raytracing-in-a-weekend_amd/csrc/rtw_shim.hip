@@ -594,7 +594,8 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
         for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
         for (int k = 3; k < 5; k++) { stats->phase_steps[k] = h_stats[16 + 2 * (k - 3)]; stats->phase_lanes[k] = h_stats[17 + 2 * (k - 3)]; }
 #if defined(RTW_STAMP) || defined(RTW_ENDTIMES)     // diagnostic builds only (scripts/gpu_endtimes.py)
-        if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu\n", h_stats[11], h_stats[12], h_stats[13]);
+        if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu   of shade: hit %llu, bank + next unit %llu, camera ray %llu, query begin %llu\n",
+                                                   h_stats[11], h_stats[12], h_stats[13], h_stats[16], h_stats[17], h_stats[18], h_stats[19]);
         if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15] && getenv("RTW_ENDTIMES_REF")) {
             std::fprintf(stderr, "rtw endtimes histogram (waves ending in each 1/32 of the reference lifetime, bins 21/32 .. 32/32+; bin 0 also holds everything earlier):");
             for (int k = 0; k < 12; k++) std::fprintf(stderr, " %llu", h_stats[20 + k]);
