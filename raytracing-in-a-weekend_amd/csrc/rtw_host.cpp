@@ -662,7 +662,9 @@ void build_bvh(const RtwSphere *spheres, uint32_t n, float t_begin, float t_end,
                 b.plane[0][k][0] = half_bits(a.lo0[k], false); b.plane[0][k][1] = half_bits(a.hi0[k], true);
                 b.plane[1][k][0] = half_bits(a.lo1[k], false); b.plane[1][k][1] = half_bits(a.hi1[k], true);
             }
-            b.c0 = (int16_t)a.c0; b.c1 = (int16_t)a.c1; b.pad = 0;
+            // child references as the traversal consumes them: a leaf as ~sphere (negative), an inner node as its BYTE OFFSET in the
+            // f16 array (id * 32 <= 16352 < the END / DEAD codes 0x7FFE / 0x7FFF): with the array at LDS offset 0 that is the node's address
+            b.c0 = (int16_t)(a.c0 >= 0 ? a.c0 * 32 : a.c0); b.c1 = (int16_t)(a.c1 >= 0 ? a.c1 * 32 : a.c1); b.pad = 0;
         }
     }
 }
@@ -832,7 +834,7 @@ extern "C" int rtw_bvh_validate(const RtwScene *sc, float t_begin, float t_end, 
                     const BvhNode16 &h = b.nodes16[it.ref];
                     const float l16 = half(h.plane[c][k][0]), h16 = half(h.plane[c][k][1]);
                     if (!(l16 <= ch.lo[k] && h16 >= ch.hi[k])) return RTW_E_INVALID;
-                    if ((int32_t)(c ? h.c1 : h.c0) != ch.ref) return RTW_E_INVALID;
+                    if ((int32_t)(c ? h.c1 : h.c0) != (ch.ref >= 0 ? ch.ref * 32 : ch.ref)) return RTW_E_INVALID;
                 }
             }
             todo.push_back(ch);

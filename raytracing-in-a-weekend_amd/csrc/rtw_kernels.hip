@@ -529,7 +529,7 @@ __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav 
             exact_sphere<MOVING>(bg[k], vv, bv.big_index[k], o, d, pt.tm, tr.a, tr.ra, a_plain, A.mint, A.maxt, tr.best, tr.best_t);
         }
     }
-    tr.node = bv.root;
+    tr.node = (sizeof(S) == 2 && bv.root > 0) ? bv.root * 32 : bv.root;         // (LDS variant: inner nodes by byte offset, trav_node_lds)
     if (tr.node == (int)0x80000000) { tr.node = (int)Code<S>::END; return; }   // no tree: the query is complete
     // per-ray constants of the thick-ray slab test.  Everything here only feeds CONSERVATIVE bounds, so
     // the hardware approximations (v_sqrt_f32 / v_rcp_f32 / v_rsq_f32, <= 1 ulp) are used with the
@@ -631,8 +631,10 @@ __device__ __forceinline__ float h_hi(unsigned int w) { return (float)__builtin_
 // global loads; the f16 planes feed v_fma_mix_f32 directly.
 __device__ __forceinline__ void trav_node_lds(const u4 *lnodes, Trav &tr) {
     const uint32_t popped = lds_get<unsigned short>(tr.sp);
-    const u4 r0 = lnodes[tr.node * 2];
-    const u3 r1 = *(const u3 *)(lnodes + tr.node * 2 + 1);     // 12 of the 16 bytes: no dead destination register for the allocator to recycle early
+    // tr.node is the node's byte offset in the f16 array (BvhNode16.c0 / c1 hold inner children that way), which sits at LDS offset 0
+    const uint32_t at = (uint32_t)tr.node;                            // (+ the array's LDS address, which is 0: checked once by the kernel)
+    const u4 r0 = lds_get<u4>(at);
+    const u3 r1 = lds_get<u3>(at + 16u);       // 12 of the 16 bytes: no dead destination register for the allocator to recycle early
 #ifdef RTW_LDS_PROBE
     {   // experiment: how much LDS headroom is there?  RTW_LDS_PROBE extra (2-byte-aligned) dword reads per visit, results only consumed
         const uint32_t pa = (uint32_t)tr.node * 32u + ((tr.selx & 1u) << RTW_LDS_PROBE_SH);
@@ -703,6 +705,9 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     *(stack_t *)(lds_raw + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t)) = (stack_t)Code<stack_t>::END;   // level 0: the sentinel (own slot, no sync needed)
     u4 *lnodes = (u4 *)lds_raw;                     // offset 0 (rtw_shim.hip: the node fetch needs no base register)
+    // ... and the dynamic LDS itself starts at LDS address 0 (the kernel has no static __shared__), so a node's byte offset IS its address
+    // (trav_node_lds).  The address is a link-time constant the compiler cannot see; should it ever not be 0 the launch fails loudly.
+    if (LDSN && lds_addr(lds_raw) != 0u) { if (threadIdx.x == 0) atomicAdd(&A.stats[23], 1ull); return; }
     f4 *lgeom = (f4 *)(lds_raw + A.lds_geom_off);
     const DevScene &sc = A.sc;
     if (LDSN) {
