@@ -63,6 +63,12 @@ __device__ __forceinline__ float sqrt_plain(float x) {
     const float t = (0.0f >= e_dn) ? s_dn : s;
     return (0.0f < e_up) ? s_up : t;
 }
+// sqrt(x), correctly rounded: the plain sequence when every active lane's x is in [2^-96, 2^127), hipcc's expansion otherwise (same bits)
+__device__ __forceinline__ float sqrt_ieee(float x) {
+    const bool plain = (__float_as_uint(x) - 0x0F800000u) < (0x7F000000u - 0x0F800000u);
+    if (__ballot(!plain) == 0ull) return sqrt_plain(x);
+    return __builtin_sqrtf(x);
+}
 __device__ __forceinline__ float rcp_refined(float d) {
     const float r = __builtin_amdgcn_rcpf(d);
     return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
@@ -277,7 +283,7 @@ __device__ __forceinline__ v3 refract(v3 uv, v3 n, float etai_over_etat) {
     float cos_theta = dot(-uv, n);
     if (cos_theta > 1.0f) cos_theta = 1.0f;
     v3 r_out_perp = (uv + n * cos_theta) * etai_over_etat;
-    v3 r_out_parallel = n * -__builtin_sqrtf(__builtin_fabsf(1.0f - len2(r_out_perp)));
+    v3 r_out_parallel = n * -sqrt_ieee(__builtin_fabsf(1.0f - len2(r_out_perp)));
     return r_out_perp + r_out_parallel;
 }
 // materials.rs:98-103, powi(5) = x * ((x*x)*(x*x))
@@ -320,7 +326,7 @@ __device__ __forceinline__ v3 on_hit(const MatP m, v3 point, v3 normal, v3 dir, 
         const float ratio = front ? m.inv_ir : m.ir;
         float ct = dot(-ud, n);
         if (ct > 1.0f) ct = 1.0f;
-        const float st = __builtin_sqrtf(1.0f - ct * ct);
+        const float st = sqrt_ieee(1.0f - ct * ct);
         const bool cannot_refract = ratio * st > 1.0f;
         const float rfl = reflectance(ct, front ? m.r0_front : m.r0_back);
         bool do_reflect = cannot_refract;
@@ -360,7 +366,7 @@ __device__ __forceinline__ v3 on_hit_rust2(const MatP m, v3 normal, v3 dir, Rng 
         const v3 ud = unit(dir);
         float ct = dot(-ud, n);
         if (ct > 1.0f) ct = 1.0f;
-        const float st = __builtin_sqrtf(1.0f - ct * ct);
+        const float st = sqrt_ieee(1.0f - ct * ct);
         const bool cannot_refract = ratio * st > 1.0f;
         const float rfl = reflectance(ct, front ? m.r0_front : m.r0_back);
         bool do_reflect = cannot_refract;

@@ -482,8 +482,9 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
 #endif
 
 struct Trav {                // traversal state of one lane
-    int node;                // the lane's PHASE is encoded here: 0 <= node < DEAD an inner node to visit (TRAVERSE); node < 0 the
-                             // leaf ~node to test (LEAF); END: no query pending, the lane waits for a SHADE step; DEAD: finished
+    int node;                // the lane's PHASE is encoded here: 0 <= node < DEAD an inner node to visit (TRAVERSE; LDS variant: its byte offset);
+                             // above END (as unsigned) the leaf ~node to test (LEAF; LDS variant: 16-bit codes, zero-extended);
+                             // END: no query pending, the lane waits for a SHADE step; DEAD: finished
     uint32_t sp;             // LDS byte ADDRESS of the TOP entry of this lane's stack, base + (level * RTW_BLOCK + threadIdx.x) * sizeof(entry);
                              // level 0 holds the END sentinel, so a pop never has to ask whether the stack is empty
     int best; float best_t;  // closest accepted hit so far (best_t starts at maxt)
@@ -500,7 +501,9 @@ template <class S> struct Code;
 template <> struct Code<short> { enum : int { END = 0x7FFF, DEAD = 0x7FFE }; };
 template <> struct Code<int> { enum : int { END = 0x7FFFFFFF, DEAD = 0x7FFFFFFE }; };
 template <class S> __device__ __forceinline__ bool in_trav(int node) { return (uint32_t)node < (uint32_t)Code<S>::DEAD; }
-__device__ __forceinline__ bool in_leaf(int node) { return node < 0; }
+template <class S> __device__ __forceinline__ bool in_leaf(int node) { return (uint32_t)node > (uint32_t)Code<S>::END; }
+// sphere index of a LEAF code: ~code, within the width of a stack entry
+template <class S> __device__ __forceinline__ uint32_t leaf_sphere(int node) { return (uint32_t)node ^ (sizeof(S) == 2 ? 0xFFFFu : 0xFFFFFFFFu); }
 template <class S> __device__ __forceinline__ bool in_shade(int node) { return node == (int)Code<S>::END; }
 
 // Lanes of the wave for which `c` holds, as a 32-bit SGPR value.  The empty asm hides the popcount's origin from the
@@ -529,8 +532,9 @@ __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav 
             exact_sphere<MOVING>(bg[k], vv, bv.big_index[k], o, d, pt.tm, tr.a, tr.ra, a_plain, A.mint, A.maxt, tr.best, tr.best_t);
         }
     }
-    tr.node = (sizeof(S) == 2 && bv.root > 0) ? bv.root * 32 : bv.root;         // (LDS variant: inner nodes by byte offset, trav_node_lds)
-    if (tr.node == (int)0x80000000) { tr.node = (int)Code<S>::END; return; }   // no tree: the query is complete
+    if (bv.root == (int)0x80000000) { tr.node = (int)Code<S>::END; return; }   // no tree: the query is complete
+    // (LDS variant: inner nodes by byte offset, trav_node_lds; every code zero-extended from 16 bits)
+    tr.node = sizeof(S) == 2 ? (bv.root >= 0 ? bv.root * 32 : (int)((uint32_t)bv.root & 0xFFFFu)) : bv.root;
     // per-ray constants of the thick-ray slab test.  Everything here only feeds CONSERVATIVE bounds, so
     // the hardware approximations (v_sqrt_f32 / v_rcp_f32 / v_rsq_f32, <= 1 ulp) are used with the
     // 1e-4 relative safety factors below instead of the correctly-rounded sequences.
@@ -577,12 +581,12 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(
 // After a leaf test: take the next entry off the stack (the sentinel of level 0 ends the query).
 template <class S>
 __device__ __forceinline__ void trav_pop(Trav &tr) {
-    tr.node = (int)lds_get<S>(tr.sp);
+    tr.node = (int)(uint32_t)lds_get<typename std::make_unsigned<S>::type>(tr.sp);
     tr.sp -= RTW_BLOCK * (uint32_t)sizeof(S);      // (may step below level 0 when the sentinel came off: sp is not used again before trav_begin)
 }
 
 template <class S> __device__ __forceinline__ int entry_to_node(uint32_t raw);
-template <> __device__ __forceinline__ int entry_to_node<short>(uint32_t raw) { return (int)(short)raw; }
+template <> __device__ __forceinline__ int entry_to_node<short>(uint32_t raw) { return (int)(raw & 0xFFFFu); }   // (v_and: fast class; a sign extension is a v_bfe)
 template <> __device__ __forceinline__ int entry_to_node<int>(uint32_t raw) { return (int)raw; }
 
 // Both slab results are in: descend into the nearer child and push the farther, or pop.  Select form, no exec-mask regions:
@@ -757,7 +761,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
         // in it (RTW_S_HI) or when little traversal work is left to hide behind (RTW_T_LO); otherwise the
         // larger of the two traversal queues runs.
         const uint32_t nT = lanes_in(in_trav<stack_t>(tr.node));
-        const uint32_t nL = lanes_in(in_leaf(tr.node));
+        const uint32_t nL = lanes_in(in_leaf<stack_t>(tr.node));
         const uint32_t nS = lanes_in(in_shade<stack_t>(tr.node));
         if ((nT | nL | nS) == 0u) break;                     // every lane is DEAD
         // Safety valve of the persistent loop: a wave that has taken an absurd number of scheduler trips (the bench frame needs ~130 k per
@@ -842,8 +846,8 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             }
         } else {
             c_steps[1]++; c_lanes[1] += nL;
-            if (in_leaf(tr.node)) {
-                const uint32_t s = (uint32_t)~tr.node;
+            if (in_leaf<stack_t>(tr.node)) {
+                const uint32_t s = leaf_sphere<stack_t>(tr.node);
                 const f4 gs = geom_in_lds ? lgeom[s] : sc.geom[s];
                 exact_sphere<MOVING>(gs, MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, tr.ra, a_plain, A.mint, A.maxt, tr.best, tr.best_t);
                 tr.hi_lim = tr.best_t + tr.tau_t;
