@@ -376,3 +376,33 @@ def test_persistent_loop_safety_valve(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_valve_check.py")], env=dict(os.environ, RTW_HIP_LIB=lib), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-1500:]
     assert "accel 1 -> -7" in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2_scale", [-31, -14, 12])
+def test_sphere_tests_outside_the_plain_range(gpu, log2_scale):
+    """sphere_root() takes the plain sqrt / division sequences only while d.d is in [2^-20, 2^20] (and disc in [2^-60, 2^96]); a scene
+    scaled by 2^-14 or 2^12 (camera rays with d.d ~ 2^-28 / 2^24) sends every wave down the generic expansions instead, and at 2^-31 the
+    scattered rays (d.d ~ 1) meet discriminants around 2^-62 as well, below the per-test range.  All must give
+    the oracle's bits, in the tree kernel (sticky per-wave flag) and in the list walk (one ballot per query)."""
+    s = float(2.0 ** log2_scale)
+    scene, cam, p = small_view(R.SCENE_C2, 96, 54, 4)
+    p.gamma, p.depth = 1.0, 8
+    for i in range(scene.n_spheres):
+        sp = scene._spheres[i]
+        for k in range(3): sp.center[k] *= s
+        sp.radius *= s
+    for name in ("origin", "pixel00", "delta_u", "delta_v"):
+        v = getattr(cam, name)
+        for k in range(3): v[k] *= s
+    cam.lens_radius *= s
+    # (the ray parameter t = (-b -+ sqrt(disc)) / a does not change with the scale -- b, sqrt(disc) and a all carry 2^(2 log2_scale) -- so
+    # mint / maxt stay as they are)
+    ref, st_ref = O.render(cam, scene, p, threads=16)
+    assert st_ref.segments > 1.5 * st_ref.camera_rays      # the scaled scene still scatters
+    gpu.set_scene(scene)
+    for accel in (R.ACCEL_BVH, R.ACCEL_BRUTE):
+        p.accel = accel
+        img, st = gpu.render(cam, p)
+        assert st.segments == st_ref.segments and np.array_equal(img, ref), (log2_scale, accel)
+        assert (st.node_tests > 0) == (accel == R.ACCEL_BVH)
