@@ -6,6 +6,7 @@ TAG=${1:-r01}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
+echo "$*" > $OUT/bench_args.txt
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1

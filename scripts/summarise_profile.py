@@ -88,7 +88,9 @@ if m("FETCH_SIZE") is not None and m("WRITE_SIZE") is not None:
                    hbm_bytes_per_step_note="render + resolve; FETCH_SIZE/WRITE_SIZE are in KB; FETCH_SIZE doubled per the gfx950 "
                                            "correction (MI355X_MICROARCH.md HBM)")
 
-summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+_args_file = os.path.join(src, "bench_args.txt")
+_extra = open(_args_file).read().strip() if os.path.exists(_args_file) else ""
+summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline" + (" " + _extra if _extra else "") +
                       "   (then one --pmc pass per counter group, same command; scripts/profile_bench.sh, scripts/profile_pmc2.sh; "
                       "summarised by scripts/summarise_profile.py)",
            "kernel_stats": kstats, "dispatch": dispatch, "pmc": dict(sorted(pmc.items())), "derived": derived}
