@@ -70,10 +70,14 @@ static inline v3 v3_reflect(v3 a, v3 n) { return v3_sub(a, v3_scale(v3_scale(n, 
 static inline int v3_close_to_zero(v3 a) { return fabsf(a.x) < 1e-7f && fabsf(a.y) < 1e-7f && fabsf(a.z) < 1e-7f; }
 
 /* ------------------------------------------------------------------------------------------------
- * RNG.  NOT the reference's (see header).  One stream per (seed, pixel, sample): a 32-bit PCG
- * (RXS-M-XS output) whose start state AND odd increment come from a lowbias32 hash chain, so the
- * image does not depend on how pixels are partitioned over threads / lanes / GPUs.
- * xi = (u32 >> 8) * 2^-24 in [0,1): the mapping rand 0.8.5 `Standard` uses for f32.
+ * RNG.  NOT the reference's (see header).  One short stream per (seed, pixel, sample): a 32-bit LCG
+ * (x <- 747796405 x + inc mod 2^32, the PCG family's multiplier) whose start state AND odd increment
+ * come from a lowbias32 hash chain, so the image does not depend on how pixels are partitioned over
+ * threads / lanes / GPUs.  A draw is the TOP 24 bits of the state (the strong bits of a power-of-two
+ * LCG), xi = (x >> 8) * 2^-24 in [0,1): the mapping rand 0.8.5 `Standard` uses for f32.  (Rounds 1-2a
+ * ran PCG's RXS-M-XS output permutation on top; on the GPU those 7 extra integer instructions per
+ * draw were 9 % of the frame -- DESIGN.md "RNG" -- and tests/test_rng_quality.py finds nothing they
+ * bought for streams this short and this well separated.)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct { uint32_t state, inc; } rng_t;
 
@@ -92,8 +96,7 @@ static inline rng_t rng_seed(uint64_t seed, uint32_t pixel, uint32_t sample) {
 static inline uint32_t rng_u32(rng_t *r) {
     uint32_t old = r->state;
     r->state = old * 747796405U + r->inc;
-    uint32_t word = ((old >> ((old >> 28) + 4U)) ^ old) * 277803737U;
-    return (word >> 22) ^ word;
+    return old;
 }
 static inline float rng_f32(rng_t *r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
 

@@ -125,8 +125,11 @@ __device__ __forceinline__ bool close_to_zero(v3 a) {
     return __builtin_fabsf(a.x) < 1e-7f && __builtin_fabsf(a.y) < 1e-7f && __builtin_fabsf(a.z) < 1e-7f;
 }
 
-// ---- RNG: 32-bit PCG (RXS-M-XS) with a per-stream odd increment, seeded by a lowbias32 hash chain
-// of (seed, pixel, sample).  Same definition as oracle/rtw_oracle.c (independently written there).
+// ---- RNG: one short stream per (seed, pixel, sample): a 32-bit LCG (the PCG family's multiplier) with a per-stream odd increment, start
+// state and increment from a lowbias32 hash chain; a draw is the top 24 bits of the state.  Same definition as oracle/rtw_oracle.c
+// (independently written there).  Until the middle of round 2 PCG's RXS-M-XS output permutation ran on top: 7 more integer instructions
+// per draw, ~27 draws per SHADE step of a wave = 9 % of the frame (profiles/r02_ab_rng_cost.log), and nothing measurable in return for
+// streams of a few dozen draws from hashed starts (tests/test_rng_quality.py; DESIGN.md "RNG").
 struct Rng { uint32_t state, inc; };
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -145,11 +148,9 @@ __device__ __forceinline__ Rng rng_start(uint32_t base, uint32_t sample) {
 }
 // the top 24 bits of the next output, as a float: n in [0, 2^24), exact
 __device__ __forceinline__ float rng_n24(Rng &r) {
-    uint32_t old = r.state;
+    const uint32_t old = r.state;
     r.state = old * 747796405U + r.inc;
-    uint32_t word = ((old >> ((old >> 28) + 4U)) ^ old) * 277803737U;
-    word = (word >> 22) ^ word;
-    return (float)(word >> 8);
+    return (float)(old >> 8);
 }
 __device__ __forceinline__ float rng_f32(Rng &r) { return rng_n24(r) * (1.0f / 16777216.0f); }
 // xi * 2 + (-1) and c + xi in ONE instruction each: n * 2^-k is exact (n < 2^24, power-of-two scale), so the fused
