@@ -694,17 +694,17 @@ __device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr) {
 #define RTW_BVH_WAVES_GEOM 2   /* 4 (128 VGPRs, 26 dwords of scratch) measured: no gain */
 #endif
 #ifndef RTW_BVH_WAVES_SPEC
-#define RTW_BVH_WAVES_SPEC 6
+#define RTW_BVH_WAVES_SPEC 6   /* the specialised builds (SPEC != 0) are compiled for 6 waves/SIMD = 80 VGPRs: what the LDS allows at six workgroups per CU */
 #endif
 // NODES: 0 = f32 nodes in global memory, 32-bit stack; 1 = f16 nodes in LDS, 16-bit stack; 2 = as 1, and the spheres' {centre, r^2} in LDS
 // too (a build of its own: as a run-time choice the leaf test went through a flat load and a select of two addresses, 7 VALU).
 template <bool MOVING, int NODES, int SPEC, bool GEOM>
 __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ? RTW_BVH_WAVES_SPEC : RTW_BVH_WAVES)) void render_bvh(const KArgs A) {
     constexpr bool LDSN = NODES != 0, geom_in_lds = NODES == 2;
-    // LDS is all dynamic, sized by the host for THIS tree (rtw_ctx_render): the per-lane traversal stack
-    // [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel, one per tree level, and the slot
-    // above the top that the select-form descend always writes; 16-bit entries in the LDS-node variant), then -- LDS-node variant -- the f16 nodes and, when it does not cost a resident workgroup,
-    // {centre, r^2} of every sphere for the leaf tests.  Book-1: 6 KB + 15.5 KB (+ 7.8 KB).
+    // LDS is all dynamic, sized by the host for THIS tree (rtw_shim.hip, render_enqueue_impl): -- LDS-node variants -- the f16 nodes at
+    // offset 0, then the per-lane traversal stack [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel,
+    // one per tree level, and the slot above the top that the select-form descend always writes; 16-bit entries in the LDS-node
+    // variants), then -- NODES == 2 -- {centre, r^2} of every sphere for the leaf tests.  Book-1: 15.5 KB + 7 KB (+ 7.8 KB).
     typedef typename std::conditional<LDSN, short, int>::type stack_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     *(stack_t *)(lds_raw + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t)) = (stack_t)Code<stack_t>::END;   // level 0: the sentinel (own slot, no sync needed)
