@@ -44,6 +44,7 @@ struct KArgs {
     uint32_t row_block, part_index, part_count;
     uint32_t tiles_x;             // ceil(width / 8)
     uint32_t total_work;          // 64 * n_tiles * n_chunks
+    uint32_t grab_shift, grab_max;   // a wave takes min(grab_max, (work left >> grab_shift) rounded down to whole blocks, at least one block) items per queue atomic
     const uint32_t *tile_order;   // queue position -> tile (a permutation of [0, n_tiles)), or null = raster order
     uint32_t n_samples;           // rays per pixel actually traced (sampler-dependent)
     uint32_t s_root;              // strata per axis (STRATIFIED / CENTRES)

@@ -62,6 +62,7 @@ struct rtw_ctx {
     uint32_t opt_blocks_per_cu = 0;
     uint32_t opt_list_walk_max = RTW_LIST_WALK_MAX_DEFAULT;
     uint32_t opt_tile_order = 2;         // measured: profiles/r02_order_chunk_grid.log
+    uint32_t opt_grab_blocks = 2;        // RTW_OPT_GRAB_BLOCKS (profiles/r02_grab_sweep.log: 1 / 2 / 4 / 8 / a tile's 42 blocks = 83.9 / 82.9 / 83.7 / 86.8 / 107.9 ms on the bench frame)
 
     // cache of a per-call driver query (tens of microseconds: visible on small frames)
     std::map<std::pair<const void *, uint32_t>, uint32_t> occupancy;    // (kernel, dynamic LDS bytes) -> resident workgroups per CU
@@ -560,6 +561,13 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         uint32_t grid = (uint32_t)c->n_cu * wg_per_cu;
         const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
         if (grid > need) grid = need ? need : 1;
+        {   // guided grabs (fetch_pixel): work left / (4 x resident waves), as a shift; at most RTW_OPT_GRAB_BLOCKS blocks (0: the blocks of one tile)
+            const uint32_t waves4 = grid * (RTW_BLOCK / 64u) * 4u;
+            a.grab_shift = 0; while (a.grab_shift < 31u && (1u << a.grab_shift) < waves4) a.grab_shift++;
+            uint32_t blocks = c->opt_grab_blocks ? c->opt_grab_blocks : a.n_chunks;
+            if (blocks > a.n_chunks) blocks = a.n_chunks;
+            a.grab_max = (blocks ? blocks : 1u) * 64u;
+        }
         HIP_TRY(hipMemsetAsync(c->d_queue, 0, 64, c->stream));
         if (a.n_tiles) launch_render(a, c->sc.moving != 0, accel, grid, c->stream);
         HIP_TRY(hipGetLastError());
@@ -632,6 +640,7 @@ int rtw_ctx_set_option(rtw_ctx *c, uint32_t key, double v) {
     case RTW_OPT_BLOCKS_PER_CU:  if (!(v >= 0.0 && v <= 8.0)) return RTW_E_INVALID; c->opt_blocks_per_cu = (uint32_t)v; return RTW_OK;
     case RTW_OPT_LIST_WALK_MAX:  if (!(v >= 0.0 && v <= 4294967295.0)) return RTW_E_INVALID; c->opt_list_walk_max = (uint32_t)v; return RTW_OK;
     case RTW_OPT_TILE_ORDER:     if (!(v >= 0.0 && v <= 3.0 && v == (double)(uint32_t)v)) return RTW_E_INVALID; c->opt_tile_order = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_GRAB_BLOCKS:    if (!(v >= 0.0 && v <= 65536.0 && v == (double)(uint32_t)v)) return RTW_E_INVALID; c->opt_grab_blocks = (uint32_t)v; return RTW_OK;
     default: return RTW_E_INVALID;
     }
 }
