@@ -849,14 +849,18 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
         } else if (!run_leaf) {
             // RTW_TRAV_UNROLL node visits per scheduling decision: the scheduler's ballots and branches are
             // paid once per burst; lanes that leave TRAVERSE (leaf reached / query done) sit out the rest of it.
-            uint32_t live = nT;
+            // (the burst's census is summed in two scalars of its own and added once: kept in c_steps / c_lanes directly, the register
+            // allocator -- out of SGPRs in this kernel -- holds the totals in VGPRs and every visit paid a v_add for each)
+            uint32_t live = nT, b_steps = 0, b_lanes = 0;
             for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
-                c_steps[0]++; c_lanes[0] += live;
+                b_steps++; b_lanes += live;
                 if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr); else trav_node(A.bvh, tr); }
                 if (u + 1 >= RTW_TRAV_UNROLL) break;
                 live = lanes_in(in_trav<stack_t>(tr.node));
                 if (live == 0u) break;
             }
+            asm volatile("" : "+s"(b_steps), "+s"(b_lanes));
+            c_steps[0] += b_steps; c_lanes[0] += b_lanes;
         } else {
             c_steps[1]++; c_lanes[1] += nL;
             if (in_leaf<stack_t>(tr.node)) {
