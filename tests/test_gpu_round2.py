@@ -406,3 +406,32 @@ def test_sphere_tests_outside_the_plain_range(gpu, log2_scale):
         img, st = gpu.render(cam, p)
         assert st.segments == st_ref.segments and np.array_equal(img, ref), (log2_scale, accel)
         assert (st.node_tests > 0) == (accel == R.ACCEL_BVH)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [0, 1, 2, 5])
+def test_grab_size_never_changes_the_image(rtw, blocks):
+    """RTW_OPT_GRAB_BLOCKS only changes how many 64-unit blocks a wave takes from the work queue per atomic (0: up to a tile's worth):
+    full frames, banded renders and row partitions are bit-identical, with both kernels, for a frame large enough that the guided rule
+    really hands out several blocks at a time, and every unit is rendered exactly once (camera-ray count)."""
+    scene, cam, p = small_view(R.SCENE_C2, 320, 184, 40)
+    p.gamma, p.depth = 1.0, 6
+    with rtw.Renderer(0) as r:
+        r.set_scene(scene)
+        r.set_option(R.OPT_GRAB_BLOCKS, 1)
+        p.accel = R.ACCEL_BVH
+        ref, st_ref = r.render(cam, p)                            # (single blocks: the behaviour every other parity test pins to the oracle)
+        r.set_option(R.OPT_GRAB_BLOCKS, blocks)
+        for accel in (R.ACCEL_BVH, R.ACCEL_BRUTE):
+            p.accel = accel
+            img, st = r.render(cam, p)
+            assert st.camera_rays == 320 * 184 * 40 and st.segments == st_ref.segments and np.array_equal(img, ref), (blocks, accel)
+        p.accel = R.ACCEL_BVH
+        r.set_option(R.OPT_SAMPLE_BANK_GB, 0.01)                  # several bands of tile rows
+        img, _ = r.render(cam, p)
+        assert np.array_equal(img, ref)
+        r.set_option(R.OPT_SAMPLE_BANK_GB, 48)
+        p.row_block, p.part_index, p.part_count = 8, 1, 3
+        part, _ = r.render(cam, p)
+        rows = [j for j in range(184) if (j // 8) % 3 == 1]
+        assert np.array_equal(part, ref[rows])
