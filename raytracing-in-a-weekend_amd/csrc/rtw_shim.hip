@@ -428,7 +428,7 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         // 13.34 / 13.55, C2 (51 per lane) in 8.97 / 9.17 / 9.37.  A frame so small that one workgroup per CU is enough (below) gets
         // units of 2 (C1: 0.276 -> 0.261 ms).
         const uint64_t units4 = (uint64_t)a.tiles_x * ((n_rows + 7) / 8) * ((a.n_samples + 3) / 4) * 64ull;
-        const uint64_t lanes = (uint64_t)c->n_cu * RTW_BLOCK * 6ull;
+        const uint64_t lanes = (uint64_t)c->n_cu * 1536ull;       // 24 resident waves per CU (6 per SIMD: the register budget of the specialised builds)
         // (units of 12 from 500 per lane: bench frame 97.8 -> 97.0 ms, C4 386.1 -> 383.7; 16..32 gain C4 another 0.6 % and lose the bench frame 0.3..0.9 %)
         chunk_len = units4 >= 500ull * lanes ? 12u : units4 >= 200ull * lanes ? 8u : units4 >= 64ull * lanes ? 6u : (units4 * 6ull < 16ull * lanes ? 2u : 4u);
     }
@@ -491,9 +491,9 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         off += levels * RTW_BLOCK * (ldsn ? 2u : 4u);
         off = (off + 15u) & ~15u;
         if (ldsn) {
-            // sphere geometry rides along only while the workgroup stays under 1/6 of the CU's 160 KiB, i.e. while
+            // sphere geometry rides along only while the workgroup stays under its share (1/6 with 256 threads) of the CU's 160 KiB, i.e. while
             // it does not cost a resident workgroup at the kernel's register budget (6 waves/SIMD)
-            bool geom = off + c->sc.n * 16u <= 160u * 1024u / 6u;
+            bool geom = off + c->sc.n * 16u <= 160u * 1024u / (1536u / RTW_BLOCK);
             if (c->opt_lds_geom >= 0) geom = c->opt_lds_geom != 0 && c->sc.n <= RTW_LDS_GEOM_MAX;
             if (geom && kernel_has_lds_geom(a)) { a.lds_geom_off = off; off += c->sc.n * 16u; }
         }
