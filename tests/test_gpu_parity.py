@@ -34,6 +34,15 @@ def render_both(gpu, scene, cam, p, threads=16):
     for accel in BOTH:
         p.accel = accel
         out[accel] = gpu.render(cam, p)
+    # Since round 2 a BVH request on a scene of <= 48 spheres is routed to the list-walk kernel (RTW_OPT_LIST_WALK_MAX): render
+    # once more with the tree FORCED, so that the traversal kernels (all of render_bvh's builds, the GEOM ones included) keep
+    # being compared with the oracle on the small scenes most of these tests use.
+    gpu.set_option(R.OPT_LIST_WALK_MAX, 0)
+    try:
+        p.accel = R.ACCEL_BVH
+        out["tree forced"] = gpu.render(cam, p)
+    finally:
+        gpu.set_option(R.OPT_LIST_WALK_MAX, 48)
     return ref, st_ref, out
 
 
