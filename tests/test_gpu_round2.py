@@ -435,3 +435,52 @@ def test_grab_size_never_changes_the_image(rtw, blocks):
         part, _ = r.render(cam, p)
         rows = [j for j in range(184) if (j // 8) % 3 == 1]
         assert np.array_equal(part, ref[rows])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("moving", [False, True])
+@pytest.mark.parametrize("textured", [False, True])
+def test_every_build_of_the_traversal_kernel(gpu, moving, textured):
+    """render_bvh is compiled 28 times (MOVING x NODES {global f32 nodes, LDS f16 nodes, LDS nodes + LDS sphere geometry} x SPEC
+    {generic, common, textured, chunk sums} + the GEOM builds); which build a request runs depends on the scene's size, motion and
+    textures, on the integrator and on three knobs.  A scene of 130 spheres (small enough for its geometry to fit in LDS, large
+    enough to be given to the tree) is rendered through every build it can reach and each image compared with the oracle."""
+    rng = np.random.default_rng(5 + 2 * moving + textured)
+    tex = rng.uniform(0.1, 0.9, size=(4, 6, 3)).astype(np.float32)
+    mats = [R.SCATTER_M, R.METALLIC_M, R.GLASS_M, R.FUZZY3_M]
+    ground = R.Sphere.new_with_texture((0, -1000, 0), 1000.0, None, R.SCATTER_M, 0) if textured else R.Sphere.with_albedo((0, -1000, 0), 1000.0, (0.5, 0.5, 0.5))
+    spheres = [ground]
+    for i in range(129):
+        c = (float(rng.uniform(-5, 5)), float(rng.uniform(0.15, 1.0)), float(rng.uniform(-6, 1)))
+        vel = (0.0, float(rng.uniform(0.0, 6.0)), 0.0) if (moving and i % 3 == 0) else None
+        spheres.append(R.Sphere.with_albedo(c, float(rng.uniform(0.1, 0.3)), tuple(rng.uniform(0.3, 0.9, 3)), mats[i % 4], velocity=vel))
+    scene = R.Scene(spheres, textures=[tex] if textured else [])
+    vp = R.Viewport.new_from_res(112, 64, 6, 8, 1.0, vfov=45.0, origin=(0.0, 1.6, 6.0), direction=(0.0, -0.2, -1.0), lens_radius=0.03)
+    if moving: vp.shutter_speed, vp.fps = 1.0 / 30.0, 30.0
+    cam = vp.camera()
+    gpu.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
+
+    def close(img, ref):
+        if not textured: return np.array_equal(img, ref)
+        same = (img == ref).all(axis=2)                       # (atan2f / acosf: a hit may fall on the other side of a texel edge)
+        return same.mean() > 0.998 and np.abs(img - ref).max() < 1.0
+
+    seen = set()
+    for integrator in (R.INTEGRATOR_GRADIENT, R.INTEGRATOR_NORMAL):          # SPEC 1 / 2 builds, and the generic build
+        for flags in (0, R.FLAG_CHUNK_SUMS):                                   # ... SPEC 3 (gradient, untextured) or generic
+            p = vp.params(integrator, R.SAMPLER_ROW)
+            p.gamma, p.flags = 1.0, flags
+            ref, st_ref = O.render(cam, scene, p, threads=16)
+            for lds_geom in (0, 1):                                            # NODES 1 / 2
+                for extra in (0, R.FLAG_GLOBAL_NODES):                         # NODES 0
+                    gpu.set_option(R.OPT_LDS_GEOM, lds_geom)
+                    p.accel, p.flags = R.ACCEL_BVH, flags | extra
+                    img, st = gpu.render(cam, p)
+                    assert st.node_tests > 0 and st.segments == st_ref.segments, (integrator, flags, lds_geom, extra)
+                    assert close(img, ref), (integrator, flags, lds_geom, extra)
+                    seen.add((integrator, flags, lds_geom, extra))
+            p.accel, p.flags = R.ACCEL_BRUTE, flags
+            img, st = gpu.render(cam, p)
+            assert st.segments == st_ref.segments and close(img, ref)
+    gpu.set_option(R.OPT_LDS_GEOM, -1)
+    assert len(seen) == 16
