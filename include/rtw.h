@@ -270,12 +270,14 @@ enum {
     RTW_OPT_LIST_WALK_MAX    = 5, /* RTW_ACCEL_BVH requests for scenes with at most this many spheres walk the list
                                      instead (result-invariant; the traversal scheduler only costs there).  Default:
                                      the measured crossover; 0 = always use the tree                     */
-    RTW_OPT_TILE_ORDER       = 6, /* order in which the 8x8 tiles enter the work queue: 0 raster; 1 groups of 8 tiles
-                                     scattered over the frame; 2 (default) expensive tiles first by a cost estimated from each tile's
-                                     centre ray (sphere field / ground only / sky, nearer first), raster for scenes with quads or
-                                     instances; 3 reverse raster                                                            */
-    RTW_OPT_GRAB_BLOCKS      = 7  /* 64-item blocks of the work queue a wave may take with one atomic while plenty of work is left (single
+    RTW_OPT_TILE_ORDER       = 6, /* order in which the 8x8 tiles enter the work queue: 0 (default) raster; 1 groups of 8
+                                     tiles scattered over the frame; 2 expensive tiles first by a cost estimated from each tile's centre
+                                     ray (sphere field / ground only / sky, nearer first; raster for scenes with quads or instances);
+                                     3 reverse raster; 4 as 2 in 32 coarse steps per class, raster inside a step                      */
+    RTW_OPT_GRAB_BLOCKS      = 7, /* 64-item blocks of the work queue a wave may take with one atomic while plenty of work is left (single
                                      blocks towards the end of a launch): default 2; 1 = always one; 0 = up to one tile's blocks      */
+    RTW_OPT_SUB_QUEUES       = 8  /* 0 (default): the work queue is eight sub-queues with a counter each (a wave starts on the one of its
+                                     XCD and helps out on the others when it is empty), a single one for tiny launches; 1: always single */
 };
 int  rtw_ctx_set_option(rtw_ctx *ctx, uint32_t key, double value);
 

@@ -728,13 +728,16 @@ void build_tile_order(uint32_t mode, uint32_t tiles_x, uint32_t tiles_y, uint32_
     const uint32_t n = tiles_x * tiles_y;
     order.resize(n);
     if (mode == 3u) { for (uint32_t q = 0; q < n; q++) order[q] = n - 1u - q; return; }
-    if (mode != 1u && mode != 2u) { for (uint32_t q = 0; q < n; q++) order[q] = q; return; }
+    if (mode != 1u && mode != 2u && mode != 4u) { for (uint32_t q = 0; q < n; q++) order[q] = q; return; }
     const uint32_t g = 8u, ng = (n + g - 1u) / g;      // (group sizes 2..64 measure the same within noise: profiles/r02_tile_order.log)
     const std::vector<uint32_t> grp = scatter_perm(ng);
     uint32_t k = 0;
     for (uint32_t q = 0; q < ng; q++)
         for (uint32_t i = 0; i < g; i++) { const uint32_t t = grp[q] * g + i; if (t < n) order[k++] = t; }
-    if (mode != 2u || cull.n_other || (!cull.has_tree && !cull.n_big)) return;
+    if ((mode != 2u && mode != 4u) || cull.n_other || (!cull.has_tree && !cull.n_big)) {
+        if (mode == 4u) for (uint32_t q = 0; q < n; q++) order[q] = q;          // (no cost guess: raster)
+        return;
+    }
     // Mode 2: longest-processing-time-first by an ESTIMATE of a tile's cost, from its centre ray (no lens offset, no jitter):
     //   class 2  the ray enters the root box of the tree's spheres: the sphere field -- nearer means larger spheres on screen, more
     //            pixels that hit one, more inter-reflection: cost falls with the distance at which the ray reaches the ground (a big
@@ -764,6 +767,21 @@ void build_tile_order(uint32_t mode, uint32_t tiles_x, uint32_t tiles_y, uint32_
         keys[t] = kx;
     }
     std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.cls != b.cls ? a.cls > b.cls : a.dist < b.dist; });
+    if (mode == 4u) {
+        // Mode 4: the same cost order, but only as coarse as 32 buckets per class; inside a bucket the tiles keep RASTER order, so that
+        // tiles handed out one after the other are mostly neighbours in the image (their rays meet the same nodes and spheres, their
+        // bank rows are adjacent) -- the exact sort of mode 2 scatters the tiles of one distance over the whole width of the frame.
+        uint32_t b0 = 0;
+        while (b0 < n) {
+            uint32_t b1 = b0; while (b1 < n && keys[b1].cls == keys[b0].cls) b1++;
+            const uint32_t cnt = b1 - b0, per = (cnt + 31u) / 32u;
+            for (uint32_t s0 = b0; s0 < b1; s0 += per) {
+                const uint32_t s1 = std::min(b1, s0 + per);
+                std::sort(keys.begin() + s0, keys.begin() + s1, [](const Key &a, const Key &b) { return a.tile < b.tile; });
+            }
+            b0 = b1;
+        }
+    }
     for (uint32_t q = 0; q < n; q++) order[q] = keys[q].tile;
 }
 } // namespace rtw

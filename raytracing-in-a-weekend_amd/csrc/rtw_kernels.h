@@ -3,6 +3,8 @@
 #include "rtw_device.h"
 #include "rtw_host.h"
 
+#define RTW_QUEUE_BYTES 4096u   // the work queue's counters (KArgs.queue): up to 8 sub-queues ...
+#define RTW_QUEUE_STRIDE 256u   // ... bytes apart
 #ifndef RTW_BLOCK
 #define RTW_BLOCK 256   // 4 waves per workgroup
 #endif
@@ -46,6 +48,7 @@ struct KArgs {
     uint32_t row_block, part_index, part_count;
     uint32_t tiles_x;             // ceil(width / 8)
     uint32_t total_work;          // 64 * n_tiles * n_chunks
+    uint32_t sub_shift;           // the work queue is 2^sub_shift sub-queues (tiles dealt round-robin in queue order), counters RTW_QUEUE_STRIDE bytes apart
     uint32_t grab_shift, grab_max;   // a wave takes min(grab_max, (work left >> grab_shift) rounded down to whole blocks, at least one block) items per queue atomic
     const uint32_t *tile_order;   // queue position -> tile (a permutation of [0, n_tiles)), or null = raster order
     uint32_t n_samples;           // rays per pixel actually traced (sampler-dependent)

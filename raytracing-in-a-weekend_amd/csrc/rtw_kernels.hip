@@ -72,7 +72,8 @@ struct Path {             // the path a lane is tracing
 // 64 units instead of one per refill (a single word saturates near 88 dequeues/us, MI355X_MICROARCH.md).
 struct Reserve {                             // wave-uniform
     uint32_t next, end;                      // items [next, end) of ONE 64-item block: the 64 pixels of one (tile, chunk) unit
-    uint32_t limit;                          // the wave holds the queue's items [next, limit): whole 64-item blocks (fetch_pixel: guided grabs)
+    uint32_t limit;                          // the wave holds items [next, limit) of sub-queue `sub`: whole 64-item blocks (fetch_pixel: guided grabs)
+    uint32_t sub, tries;                     // the sub-queue this wave takes from, and how many sub-queues it has found empty
     uint32_t i0, k0;                         // the block's tile: first column, first compact row
     uint32_t s0, s1;                         // the block's chunk: samples [s0, s1)
     uint32_t unit;                           // tile * n_chunks + chunk: the block's place in the sample bank
@@ -90,38 +91,63 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
     if (m == 0ull) return false;
     if (rs.next == rs.end) {                                      // wave-uniform: refill the reserve
         if (rs.end == rs.limit) {
-            // ... from the global queue, with one atomic for up to grab_max / 64 consecutive blocks (default 2) while plenty of work is
-            // left -- what is left, as this wave last saw it, divided by 4 x the resident waves -- and single blocks towards the end.
-            // Consecutive blocks are consecutive sample chunks of the same 8x8 tile, so the wave's lanes stay on the same 64 pixels longer:
-            // their rays are alike and its TRAVERSE / LEAF steps run fuller (0.623 -> 0.633 / 0.505 -> 0.519 on the bench frame), and
-            // the queue word sees half the atomics: -1.2 % on the bench frame.  More blocks per grab fill the steps a little more (0.643
-            // with a whole tile's 42) but cost far more than that gains -- 4: +0 %, 8: +3 %, a tile: +29 % -- because a wave then sits on
-            // up to 17 ms of work the others cannot take, and sizes its next grab by a queue position that old (profiles/r02_grab_sweep.log).
-            uint32_t grab = ((A.total_work - rs.limit) >> A.grab_shift) & ~63u;
-            grab = grab > A.grab_max ? A.grab_max : (grab < 64u ? 64u : grab);
+            // ... from the work queue.  The queue is 2^sub_shift (8, or 1 for small launches) sub-queues, each with a counter of its own 256 B
+            // from the next: sub-queue j holds the tiles at queue positions j, j + 8, .. (so each keeps the host's order), a wave starts on
+            // sub-queue blockIdx % 8 -- workgroups go round-robin to the 8 XCDs, so that is "the XCD's own" -- and moves on to the next one
+            // when it finds one empty, until it has found all of them empty.  Why: a grab is an atomic with return value on which the
+            // whole wave waits, and 6144 waves on ONE word made that wait ~2 ms of the 83 ms frame: one more such atomic per grab on the
+            // same word costs +2.2 ms, on a word per XCD +0.4 ms (profiles/r02_ab_refill_probe.log).
+            // A grab takes up to grab_max / 64 consecutive blocks (default 2) while plenty of work is left in the sub-queue -- what is
+            // left, as this wave last saw it, divided by 4 x the waves that share it -- and single blocks towards the end and when
+            // helping out on another sub-queue.  Consecutive blocks are consecutive sample chunks of the same 8x8 tile, so the wave's
+            // lanes stay on the same 64 pixels longer: their rays are alike and its TRAVERSE / LEAF steps run fuller (0.623 -> 0.633 /
+            // 0.505 -> 0.519 on the bench frame).  More blocks per grab fill the steps a little more (0.643 with a whole tile's 42) but
+            // cost far more than that gains -- 4: +0 %, 8: +3 %, a tile: +29 % -- because a wave then sits on up to 17 ms of work the
+            // others cannot take, and sizes its next grab by a queue position that old (profiles/r02_grab_sweep.log).
+            const uint32_t n_sub = 1u << A.sub_shift;
             const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-            uint32_t base = 0;
-            if ((threadIdx.x & 63u) == leader) base = atomicAdd(A.queue, grab);
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-            rs.next = base < A.total_work ? base : A.total_work;  // total_work is a multiple of 64
-            rs.limit = A.total_work - rs.next > grab ? rs.next + grab : A.total_work;      // (no overflow: next <= total_work)
+            bool got = false;
+            while (rs.tries < n_sub) {                            // (wave-uniform; at most n_sub failed grabs in a wave's life)
+                const uint32_t total = ((A.n_tiles + n_sub - 1u - rs.sub) >> A.sub_shift) * A.n_chunks * 64u;   // items of sub-queue rs.sub
+                uint32_t grab = 64u;
+                if (rs.tries == 0u && rs.limit < total) {
+                    grab = ((total - rs.limit) >> A.grab_shift) & ~63u;
+                    grab = grab > A.grab_max ? A.grab_max : (grab < 64u ? 64u : grab);
+                }
+                uint32_t base = 0;
+                if ((threadIdx.x & 63u) == leader) base = atomicAdd(A.queue + rs.sub * (RTW_QUEUE_STRIDE / 4u), grab);
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+                if (base < total) {
+                    rs.next = base;
+                    rs.limit = total - base > grab ? base + grab : total;      // (no overflow: base < total)
+                    got = true;
+                    break;
+                }
+                rs.sub = (rs.sub + 1u) & (n_sub - 1u); rs.tries++; rs.limit = 0u;
+            }
+            if (!got) {
+                rs.next = rs.limit = 0u;                          // nothing left anywhere: avail == 0 below tells the lanes
 #ifdef RTW_ENDTIMES
-            if (!(base < A.total_work) && rs.t_dry == 0ull) rs.t_dry = wall_clock64();
+                if (rs.t_dry == 0ull) rs.t_dry = wall_clock64();
 #endif
+            }
         }
         rs.end = rs.next + (rs.next < rs.limit ? 64u : 0u);       // the next 64-item block of what this wave holds
-        // Work unit = (8x8 tile, chunk of chunk_len samples, pixel of the tile); the units of one tile are consecutive.  The
-        // block's tile and chunk are the same for its 64 items: the three integer divisions run once per block, here.
-        const uint32_t u = rs.next >> 6;
-        const uint32_t qt = u / A.n_chunks, chunk = u - qt * A.n_chunks;
-        // queue position -> tile: raster order, or any permutation the host supplies (RTW_OPT_TILE_ORDER)
-        const uint32_t tile = A.tile_order ? A.tile_order[qt] : qt;
-        rs.unit = tile * A.n_chunks + chunk;
-        const uint32_t trow = tile / A.tiles_x, tcol = tile - trow * A.tiles_x;
-        rs.i0 = tcol * 8u;
-        rs.k0 = A.k_base + trow * 8u;
-        rs.s0 = chunk * A.chunk_len;
-        rs.s1 = rs.s0 + A.chunk_len < A.n_samples ? rs.s0 + A.chunk_len : A.n_samples;
+        if (rs.next < rs.limit) {
+            // Work unit = (8x8 tile, chunk of chunk_len samples, pixel of the tile); the units of one tile are consecutive.  The
+            // block's tile and chunk are the same for its 64 items: the three integer divisions run once per block, here.
+            const uint32_t u = rs.next >> 6;                       // block of the sub-queue
+            const uint32_t lt = u / A.n_chunks, chunk = u - lt * A.n_chunks;
+            const uint32_t qt = (lt << A.sub_shift) + rs.sub;      // ... -> queue position of its tile
+            // queue position -> tile: raster order, or any permutation the host supplies (RTW_OPT_TILE_ORDER)
+            const uint32_t tile = A.tile_order ? A.tile_order[qt] : qt;
+            rs.unit = tile * A.n_chunks + chunk;
+            const uint32_t trow = tile / A.tiles_x, tcol = tile - trow * A.tiles_x;
+            rs.i0 = tcol * 8u;
+            rs.k0 = A.k_base + trow * 8u;
+            rs.s0 = chunk * A.chunk_len;
+            rs.s1 = rs.s0 + A.chunk_len < A.n_samples ? rs.s0 + A.chunk_len : A.n_samples;
+        }
     }
     const uint32_t avail = rs.end - rs.next;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -409,7 +435,7 @@ template <bool MOVING, int SPEC, bool GEOM>
 __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_GEOM_BRUTE_WAVES : 1) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
-    Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = 0;
+    Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = rs.tries = 0; rs.sub = blockIdx.x & ((1u << A.sub_shift) - 1u);
 #ifdef RTW_ENDTIMES
     rs.t_dry = 0ull;
 #endif
@@ -742,7 +768,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
                       F_DONE = 8u };     // a finished path waits for the next SHADE step to bank it
     uint32_t fl = 0u;
     Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
-    Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = 0;
+    Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = rs.tries = 0; rs.sub = blockIdx.x & ((1u << A.sub_shift) - 1u);
 #ifdef RTW_ENDTIMES
     rs.t_dry = 0ull;
 #endif

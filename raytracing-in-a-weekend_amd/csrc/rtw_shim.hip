@@ -61,7 +61,10 @@ struct rtw_ctx {
     int opt_lds_geom = -1;
     uint32_t opt_blocks_per_cu = 0;
     uint32_t opt_list_walk_max = RTW_LIST_WALK_MAX_DEFAULT;
-    uint32_t opt_tile_order = 2;         // measured: profiles/r02_order_chunk_grid.log
+    uint32_t opt_tile_order = 0;         // raster.  (The cost order, 2, was the default while units were 4 samples and grabs single blocks -- profiles/
+                                         // r02_order_chunk_grid.log --; with today's units and grabs raster is 1.2 % ahead of it on the bench frame and ahead
+                                         // on every other config too, profiles/r02_order_ab.log)
+    uint32_t opt_sub_queues = 0;         // RTW_OPT_SUB_QUEUES: 0 = eight sub-queues (one per XCD) for all but tiny launches, 1 = a single queue
     uint32_t opt_grab_blocks = 2;        // RTW_OPT_GRAB_BLOCKS (profiles/r02_grab_sweep.log: 1 / 2 / 4 / 8 / a tile's 42 blocks = 83.9 / 82.9 / 83.7 / 86.8 / 107.9 ms on the bench frame)
 
     // cache of a per-call driver query (tens of microseconds: visible on small frames)
@@ -174,7 +177,7 @@ int rtw_ctx_create(int device, rtw_ctx **out) {
     if (e == hipSuccess) { c->n_cu = prop.multiProcessorCount; e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking); }
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, RTW_QUEUE_BYTES);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_stats, RTW_N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stats, RTW_N_STATS * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) { g_last_hip = (int)e; rtw_ctx_destroy(c); return RTW_E_HIP; }
@@ -562,13 +565,14 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
         if (grid > need) grid = need ? need : 1;
         {   // guided grabs (fetch_pixel): work left / (4 x resident waves), as a shift; at most RTW_OPT_GRAB_BLOCKS blocks (0: the blocks of one tile)
-            const uint32_t waves4 = grid * (RTW_BLOCK / 64u) * 4u;
+            a.sub_shift = (c->opt_sub_queues != 1u && a.n_tiles >= 64u && grid >= 64u) ? 3u : 0u;       // one sub-queue per XCD, unless the launch is tiny
+            const uint32_t waves4 = (grid * (RTW_BLOCK / 64u) * 4u) >> a.sub_shift;
             a.grab_shift = 0; while (a.grab_shift < 31u && (1u << a.grab_shift) < waves4) a.grab_shift++;
             uint32_t blocks = c->opt_grab_blocks ? c->opt_grab_blocks : a.n_chunks;
             if (blocks > a.n_chunks) blocks = a.n_chunks;
             a.grab_max = (blocks ? blocks : 1u) * 64u;
         }
-        HIP_TRY(hipMemsetAsync(c->d_queue, 0, 64, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_queue, 0, RTW_QUEUE_BYTES, c->stream));
         if (a.n_tiles) launch_render(a, c->sc.moving != 0, accel, grid, c->stream);
         HIP_TRY(hipGetLastError());
         if (tile_rows == 0) break;
@@ -639,7 +643,8 @@ int rtw_ctx_set_option(rtw_ctx *c, uint32_t key, double v) {
     case RTW_OPT_LDS_GEOM:       if (!(v >= -1.0 && v <= 1.0)) return RTW_E_INVALID; c->opt_lds_geom = (int)v; return RTW_OK;
     case RTW_OPT_BLOCKS_PER_CU:  if (!(v >= 0.0 && v <= 8.0)) return RTW_E_INVALID; c->opt_blocks_per_cu = (uint32_t)v; return RTW_OK;
     case RTW_OPT_LIST_WALK_MAX:  if (!(v >= 0.0 && v <= 4294967295.0)) return RTW_E_INVALID; c->opt_list_walk_max = (uint32_t)v; return RTW_OK;
-    case RTW_OPT_TILE_ORDER:     if (!(v >= 0.0 && v <= 3.0 && v == (double)(uint32_t)v)) return RTW_E_INVALID; c->opt_tile_order = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_TILE_ORDER:     if (!(v >= 0.0 && v <= 4.0 && v == (double)(uint32_t)v)) return RTW_E_INVALID; c->opt_tile_order = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_SUB_QUEUES:     if (!(v == 0.0 || v == 1.0)) return RTW_E_INVALID; c->opt_sub_queues = (uint32_t)v; return RTW_OK;
     case RTW_OPT_GRAB_BLOCKS:    if (!(v >= 0.0 && v <= 65536.0 && v == (double)(uint32_t)v)) return RTW_E_INVALID; c->opt_grab_blocks = (uint32_t)v; return RTW_OK;
     default: return RTW_E_INVALID;
     }

@@ -407,7 +407,7 @@ def test_tile_order_modes_on_the_bench_frame():
     n = 240 * 135
     buf = (C.c_uint32 * n)()
     order = {}
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4):
         assert R.lib().rtw_tile_order(mode, 1920, 1080, C.byref(cam), C.byref(scene.pod), buf, n) == 0
         order[mode] = np.array(buf[:])
         assert np.array_equal(np.sort(order[mode]), np.arange(n))
@@ -417,6 +417,9 @@ def test_tile_order_modes_on_the_bench_frame():
     assert np.abs(np.diff(g[:, 0])).min() > 8 * 100                                        # consecutive groups are far apart
     rows = order[2] // 240
     assert rows[:2000].mean() > 100 and rows[-2000:].mean() < 10                            # near field first, sky (top rows) last
+    rows4 = order[4] // 240                                                                  # mode 4: the same, in coarse steps with raster runs inside
+    assert rows4[:2000].mean() > 100 and rows4[-2000:].mean() < 10
+    assert (np.diff(order[4]) > 0).mean() > 0.99 and (np.diff(order[2]) > 0).mean() < 0.9
     # without a scene there is nothing to estimate from: mode 2 keeps the scattered order of mode 1
     assert R.lib().rtw_tile_order(2, 1920, 1080, C.byref(cam), None, buf, n) == 0 and np.array_equal(np.array(buf[:]), order[1])
     # a camera that looks UP from below the ground plane region: the estimate follows the camera, not the image rows

@@ -327,7 +327,7 @@ def test_example_program_multi_gpu_entry(gpu, tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_tile_order_never_changes_the_image(rtw, mode):
     """RTW_OPT_TILE_ORDER only permutes the work queue: frames, row partitions (whose tiles map to other image rows) and banded
     renders are bit-identical under every order."""

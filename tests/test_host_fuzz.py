@@ -128,7 +128,7 @@ def test_viewport_constructor_equals_the_oracle_twin(w, h, vfov, direction, lens
 
 
 @settings(max_examples=120, **SET)
-@given(st.integers(0, 3), st.integers(1, 700), st.integers(1, 400), st.tuples(finite, finite, finite), st.booleans())
+@given(st.integers(0, 4), st.integers(1, 700), st.integers(1, 400), st.tuples(finite, finite, finite), st.booleans())
 def test_tile_order_is_always_a_permutation(mode, w, h, direction, with_scene):
     """RTW_OPT_TILE_ORDER: whatever the mode, the frame shape, the camera (also degenerate ones) and the scene, the queue order is a
     permutation of the tiles -- every tile is handed out exactly once."""
