@@ -176,9 +176,30 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
 }
 
 // Camera ray of sample px.s (the sampler loops of viewport.rs / Rust2 viewport.rs).
+// The camera (21 floats, the first 84 bytes of the kernel's argument block) is read HERE, with two scalar loads, each time a path starts --
+// not through `A.cam`: values the optimiser sees as loop invariants are loaded once and kept for the whole persistent loop, which in this
+// kernel (106 SGPRs, all in use) means spilled to lanes of a VGPR and brought back with a v_readlane -- a VALU instruction in a VALU-bound
+// kernel -- at every use.  A scalar load from the (cached) argument block costs no VALU slot.
+struct CamRegs { RtwCamera c; };
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f8v __attribute__((ext_vector_type(8)));
+static_assert(sizeof(RtwCamera) == 84 && offsetof(KArgs, cam) == 0, "start_path reads KArgs.cam as 16 + 8 dwords at offset 0");
+__device__ __forceinline__ RtwCamera load_camera() {
+    f16v lo; f8v hi;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(lo), "=s"(hi) : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
+    RtwCamera c;
+    c.origin[0] = lo[0]; c.origin[1] = lo[1]; c.origin[2] = lo[2]; c.u[0] = lo[3]; c.u[1] = lo[4]; c.u[2] = lo[5];
+    c.v[0] = lo[6]; c.v[1] = lo[7]; c.v[2] = lo[8]; c.pixel00[0] = lo[9]; c.pixel00[1] = lo[10]; c.pixel00[2] = lo[11];
+    c.delta_u[0] = lo[12]; c.delta_u[1] = lo[13]; c.delta_u[2] = lo[14]; c.delta_v[0] = lo[15]; c.delta_v[1] = hi[0]; c.delta_v[2] = hi[1];
+    c.lens_radius = hi[2]; c.time0 = hi[3]; c.shutter = hi[4];
+    return c;
+}
+
 template <int SPEC>
 __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path &pt) {
-    const v3 cam_o = ld3(A.cam.origin), p00 = ld3(A.cam.pixel00), du = ld3(A.cam.delta_u), dv = ld3(A.cam.delta_v);
+    const RtwCamera cam = load_camera();
+    const v3 cam_o = ld3(cam.origin), p00 = ld3(cam.pixel00), du = ld3(cam.delta_u), dv = ld3(cam.delta_v);
     pt.rng = rng_start(px.rng_base, px.s);
     pt.thr = mk(1.0f, 1.0f, 1.0f); pt.L = mk(0, 0, 0); pt.poison = false; pt.k = 0;
     // (single assignment of pt.o / pt.d / pt.tm at the end: stores to different members on different
@@ -194,14 +215,14 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
             jx = ((float)px.i + ((float)kx + 0.5f) / (float)A.s_root) / (float)A.width;
             jy = ((float)px.j + ((float)ly + 0.5f) / (float)A.s_root) / (float)A.height;
             random_in_unit_disk(pt.rng, rx, ry);
-            o = cam_o + mk(rx, ry, 0.0f) * A.cam.lens_radius;
+            o = cam_o + mk(rx, ry, 0.0f) * cam.lens_radius;
         } else {
             random_in_unit_disk(pt.rng, rx, ry, !SPEC && (A.flags & RTW_FLAG_CPP_DIFFUSE));   // always drawn (viewport.rs:288)
-            o = cam_o + (ld3(A.cam.u) * rx + ld3(A.cam.v) * ry) * A.cam.lens_radius;
+            o = cam_o + (ld3(cam.u) * rx + ld3(cam.v) * ry) * cam.lens_radius;
             if (samp<SPEC>(A) == RTW_SAMPLER_ROW) {              // viewport.rs:290-297
                 jx = rng_offset(pt.rng, (float)px.i);
                 jy = rng_offset(pt.rng, (float)px.j);
-                tm = A.cam.time0 + A.cam.shutter * rng_f32(pt.rng);
+                tm = cam.time0 + cam.shutter * rng_f32(pt.rng);
             } else {                                         // viewport.rs:452-470 (x outer, y inner)
                 const uint32_t sx = px.s / A.s_root, sy = px.s % A.s_root;
                 jx = (float)px.i + (((float)sx + rng_f32(pt.rng)) / (float)A.s_root);
