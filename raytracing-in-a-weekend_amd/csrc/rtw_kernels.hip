@@ -575,9 +575,34 @@ __device__ __forceinline__ uint32_t lanes_in(bool c) {
 }
 
 // Begin a closest-hit query: big spheres, per-ray constants, root (which sets the phase).
+// What a query's begin needs of DevBvh -- big_geom .. abs_max, 16 dwords -- read from the argument block with one scalar load, for the
+// reason given at load_camera().
+struct BvhBegin {
+    const f4 *big_geom; const f4 *big_vel; const uint32_t *big_index;
+    uint32_t n_big, depth; int32_t root;
+    float cx, cy, cz, centre_radius, r_max2, inv_2rmin, abs_max;
+};
+static_assert(sizeof(BvhBegin) == 64 && offsetof(DevBvh, abs_max) - offsetof(DevBvh, big_geom) == 60 && offsetof(DevBvh, big_vel) == offsetof(DevBvh, big_geom) + 8 &&
+              offsetof(DevBvh, n_big) == offsetof(DevBvh, big_geom) + 24 && offsetof(DevBvh, root) == offsetof(DevBvh, big_geom) + 32 &&
+              offsetof(DevBvh, cx) == offsetof(DevBvh, big_geom) + 36, "BvhBegin mirrors DevBvh from big_geom on");
+__device__ __forceinline__ BvhBegin load_bvh_begin() {
+    typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+    u16v r;
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(__builtin_amdgcn_kernarg_segment_ptr()),
+                 "n"(offsetof(KArgs, bvh) + offsetof(DevBvh, big_geom)));
+    BvhBegin b;
+    b.big_geom = (const f4 *)(uintptr_t)((uint64_t)r[0] | ((uint64_t)r[1] << 32));
+    b.big_vel = (const f4 *)(uintptr_t)((uint64_t)r[2] | ((uint64_t)r[3] << 32));
+    b.big_index = (const uint32_t *)(uintptr_t)((uint64_t)r[4] | ((uint64_t)r[5] << 32));
+    b.n_big = r[6]; b.depth = r[7]; b.root = (int32_t)r[8];
+    b.cx = __uint_as_float(r[9]); b.cy = __uint_as_float(r[10]); b.cz = __uint_as_float(r[11]); b.centre_radius = __uint_as_float(r[12]);
+    b.r_max2 = __uint_as_float(r[13]); b.inv_2rmin = __uint_as_float(r[14]); b.abs_max = __uint_as_float(r[15]);
+    return b;
+}
+
 template <bool MOVING, class S>
 __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav &tr, uint32_t sp0, bool a_plain_wave, bool &a_odd) {
-    const DevBvh &bv = A.bvh;
+    const BvhBegin bv = load_bvh_begin();
     const v3 o = pt.o, d = pt.d;
     tr.a = dot(d, d);
     tr.ra = rcp_refined(tr.a);
