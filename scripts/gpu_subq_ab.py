@@ -1,4 +1,6 @@
-"""One work queue or eight sub-queues (RTW_OPT_SUB_QUEUES) on every config; kernel ms, best of 3."""
+"""One work queue or eight sub-queues (RTW_OPT_SUB_QUEUES), blocks per grab (RTW_OPT_GRAB_BLOCKS) and tile order (RTW_OPT_TILE_ORDER) on every
+config; kernel ms, best of 3.  (profiles/r02_order_ab.log holds three runs of this script with different triples, one of them with a
+temporary mode "raster through the permutation table".)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +15,7 @@ for name, sid, vid, parts, shutter in cases:
     with R.Renderer(0) as r:
         r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
         res = []
-        for sq, grab, order in ((0, 2, 0), (0, 2, 5), (0, 2, 2), (0, 2, 0), (0, 2, 5)):
+        for sq, grab, order in ((1, 2, 0), (0, 2, 0), (0, 1, 0), (0, 2, 2), (0, 2, 4), (0, 2, 3)):
             r.set_option(R.OPT_SUB_QUEUES, sq); r.set_option(R.OPT_GRAB_BLOCKS, grab); r.set_option(R.OPT_TILE_ORDER, order)
             best = min(r.render(cam, p, out=out.data_ptr())[1].kernel_ms for _ in range(3))
             res.append(f"{'one' if sq else 'eight'}/grab{grab}/order{order}: {best:.3f}")
