@@ -5,6 +5,9 @@
 
 #define RTW_QUEUE_BYTES 4096u   // the work queue's counters (KArgs.queue): up to 8 sub-queues ...
 #define RTW_QUEUE_STRIDE 256u   // ... bytes apart
+#ifndef RTW_SUB_SHIFT
+#define RTW_SUB_SHIFT 3u        // log2 of the number of sub-queues (8: one per XCD; 16 and 32 measured no better, profiles/r02_subq_count.log)
+#endif
 #ifndef RTW_BLOCK
 #define RTW_BLOCK 256   // 4 waves per workgroup
 #endif

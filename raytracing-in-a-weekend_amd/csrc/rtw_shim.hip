@@ -565,7 +565,7 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
         if (grid > need) grid = need ? need : 1;
         {   // guided grabs (fetch_pixel): work left / (4 x resident waves), as a shift; at most RTW_OPT_GRAB_BLOCKS blocks (0: the blocks of one tile)
-            a.sub_shift = (c->opt_sub_queues != 1u && a.n_tiles >= 64u && grid >= 64u) ? 3u : 0u;       // one sub-queue per XCD, unless the launch is tiny
+            a.sub_shift = (c->opt_sub_queues != 1u && a.n_tiles >= 64u && grid >= 64u) ? RTW_SUB_SHIFT : 0u;       // one sub-queue per XCD, unless the launch is tiny
             const uint32_t waves4 = (grid * (RTW_BLOCK / 64u) * 4u) >> a.sub_shift;
             a.grab_shift = 0; while (a.grab_shift < 31u && (1u << a.grab_shift) < waves4) a.grab_shift++;
             uint32_t blocks = c->opt_grab_blocks ? c->opt_grab_blocks : a.n_chunks;
