@@ -921,18 +921,34 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
         } else if (!run_leaf) {
             // RTW_TRAV_UNROLL node visits per scheduling decision: the scheduler's ballots and branches are
             // paid once per burst; lanes that leave TRAVERSE (leaf reached / query done) sit out the rest of it.
-            // (the burst's census is summed in two scalars of its own and added once: kept in c_steps / c_lanes directly, the register
-            // allocator -- out of SGPRs in this kernel -- holds the totals in VGPRs and every visit paid a v_add for each)
-            uint32_t live = nT, b_steps = 0, b_lanes = 0;
-            for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
-                b_steps++; b_lanes += live;
-                if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr); else trav_node(A.bvh, tr); }
-                if (u + 1 >= RTW_TRAV_UNROLL) break;
-                live = lanes_in(in_trav<stack_t>(tr.node));
+            // Bursts follow one another without a trip through the scheduler while MORE THAN HALF of the lanes are still in TRAVERSE: with
+            // 33 or more lanes there, LEAF and SHADE hold at most 31 between them, so neither "nL > nT" nor "nS >= RTW_S_HI" (52) can be true
+            // and the scheduler would say TRAVERSE again -- the same decisions from one ballot instead of three, and without the register
+            // copies the compiler puts at the joins of the three-way branch for state that only LEAF and SHADE change (~16 v_mov per burst).
+            static_assert(RTW_S_HI > 31u && RTW_T_LO <= 33u, "the shortcut below assumes the thresholds of the scheduler");
+            uint32_t live = nT;
+            for (;;) {
+                // (the burst's census is summed in two scalars of its own and added once: kept in c_steps / c_lanes directly, the register
+                // allocator -- out of SGPRs in this kernel -- holds the totals in VGPRs and every visit paid a v_add for each)
+                uint32_t b_steps = 0, b_lanes = 0;
+                for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
+                    b_steps++; b_lanes += live;
+                    if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr); else trav_node(A.bvh, tr); }
+                    if (u + 1 >= RTW_TRAV_UNROLL) break;
+                    live = lanes_in(in_trav<stack_t>(tr.node));
+                    if (live == 0u) break;
+                }
+                asm volatile("" : "+s"(b_steps), "+s"(b_lanes));
+                c_steps[0] += b_steps; c_lanes[0] += b_lanes;
+#ifdef RTW_STAMP
+                break;                                       // (diagnostic build: every burst is timed as a trip of the outer loop)
+#else
                 if (live == 0u) break;
+                live = lanes_in(in_trav<stack_t>(tr.node));
+                if (live < 33u) break;
+                if (++trips > RTW_MAX_TRIPS) break;          // (the outer loop's valve fires on its next trip)
+#endif
             }
-            asm volatile("" : "+s"(b_steps), "+s"(b_lanes));
-            c_steps[0] += b_steps; c_lanes[0] += b_lanes;
         } else {
             c_steps[1]++; c_lanes[1] += nL;
             if (in_leaf<stack_t>(tr.node)) {
