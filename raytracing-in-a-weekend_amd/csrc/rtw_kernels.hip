@@ -424,9 +424,8 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
         float disc = b * b - a * c;
         if (!(disc < 0.0f)) {
             const float x = sphere_root(b, disc, a, ra, a_plain, mint);
-            if (!(x < mint || x > maxt)) {
-                if (best < 0 || best_t > x) { best = (int)s; best_t = x; }
-            }
+            const bool take = !(x < mint || x > maxt) && (best < 0 || best_t > x);      // (select form: no exec-mask regions)
+            best = take ? (int)s : best; best_t = take ? x : best_t;
         }
     };
     const f4 zero = { 0, 0, 0, 0 };
@@ -508,9 +507,9 @@ __device__ __forceinline__ void exact_sphere(f4 g, f4 vv, uint32_t s, v3 o, v3 d
     float disc = b * b - a * c;
     if (!(disc < 0.0f)) {
         const float x = sphere_root(b, disc, a, ra, a_plain, mint);
-        if (!(x < mint || x > maxt)) {
-            if (x < best_t || (x == best_t && s < (uint32_t)best)) { best = (int)s; best_t = x; }
-        }
+        // (select form, no exec-mask regions: a NaN root fails `x < best_t` and `x == best_t` alike, as it does in the nested form)
+        const bool take = !(x < mint || x > maxt) && (x < best_t || (x == best_t && s < (uint32_t)best));
+        best = take ? (int)s : best; best_t = take ? x : best_t;
     }
 }
 
