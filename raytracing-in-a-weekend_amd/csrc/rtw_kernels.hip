@@ -778,7 +778,8 @@ __device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr) {
 #define RTW_BVH_WAVES_GEOM 2   /* 4 (128 VGPRs, 26 dwords of scratch) measured: no gain */
 #endif
 #ifndef RTW_BVH_WAVES_SPEC
-#define RTW_BVH_WAVES_SPEC 6   /* the specialised builds (SPEC != 0) are compiled for 6 waves/SIMD = 80 VGPRs: what the LDS allows at six workgroups per CU */
+#define RTW_BVH_WAVES_SPEC 7   /* the specialised builds (SPEC != 0) are compiled for 7 waves/SIMD = 72 VGPRs (two dwords of scratch in the static builds, ten in the MOVING
+                                  ones); whether the seventh workgroup per CU is used depends on the LDS the tree needs and on the size of the launch (rtw_shim.hip) */
 #endif
 // NODES: 0 = f32 nodes in global memory, 32-bit stack; 1 = f16 nodes in LDS, 16-bit stack; 2 = as 1, and the spheres' {centre, r^2} in LDS
 // too (a build of its own: as a run-time choice the leaf test went through a flat load and a select of two addresses, 7 VALU).
