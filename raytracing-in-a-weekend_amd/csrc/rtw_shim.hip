@@ -562,9 +562,10 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
             if (want < wg_per_cu) wg_per_cu = (uint32_t)(want ? want : 1);
             // The specialised BVH builds are compiled for 7 waves/SIMD (72 VGPRs); the seventh workgroup per CU pays on the full 1080p frames
             // (bench frame 77.9 -> 76.4 ms, C4 319 -> 311, C5 96.8 -> 95.0) and costs on shorter launches (an eighth of the bench frame 10.9 ->
-            // 11.1 ms, C2 7.18 -> 7.35: one more wave per SIMD to drain at the end): it is used from ~100 work units per lane
-            // (profiles/r02_ab_waves7.log).
-            if (wg_per_cu > 6u && (uint64_t)a.total_work < 100ull * c->n_cu * RTW_BLOCK * wg_per_cu) wg_per_cu = 6u;
+            // 11.1 ms, C2 7.18 -> 7.35: one more wave per SIMD to drain at the end): it is used from ~40 work units per lane
+            // (profiles/r02_ab_waves7.log; profiles/r02_wg_per_cu.log: 6 / 7 workgroups per CU = 78.2 / 76.1 ms for the bench frame, 39.8 / 38.8 for
+            // half of it, 20.75 / 20.40 for a quarter, 10.95 / 10.95 for an eighth, 7.07 / 7.11 for C2).
+            if (wg_per_cu > 6u && (uint64_t)a.total_work < 40ull * c->n_cu * RTW_BLOCK * wg_per_cu) wg_per_cu = 6u;
         }
         uint32_t grid = (uint32_t)c->n_cu * wg_per_cu;
         const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
