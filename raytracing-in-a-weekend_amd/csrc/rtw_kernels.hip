@@ -845,7 +845,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
         // SHADE is the expensive step (several hundred instructions): it runs when enough lanes have piled up
         // in it (RTW_S_HI) or when little traversal work is left to hide behind (RTW_T_LO); otherwise the
         // larger of the two traversal queues runs.
-        const uint32_t nT = lanes_in(in_trav<stack_t>(tr.node));
+        uint32_t nT = lanes_in(in_trav<stack_t>(tr.node));
         const uint32_t nL = lanes_in(in_leaf<stack_t>(tr.node));
         const uint32_t nS = lanes_in(in_shade<stack_t>(tr.node));
         if ((nT | nL | nS) == 0u) break;                     // every lane is DEAD
@@ -918,45 +918,54 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             // Wave-uniform and STICKY: lanes of this wave still test leaves of queries begun in earlier SHADE steps, so once any lane's d.d
             // has left [2^-20, 2^20] the wave stays on the generic sqrt / division (same bits, a few more instructions) for good.
             if (__ballot(a_odd) != 0ull) a_plain = false;
-        } else if (!run_leaf) {
-            // RTW_TRAV_UNROLL node visits per scheduling decision: the scheduler's ballots and branches are
-            // paid once per burst; lanes that leave TRAVERSE (leaf reached / query done) sit out the rest of it.
-            // Bursts follow one another without a trip through the scheduler while MORE THAN HALF of the lanes are still in TRAVERSE: with
-            // 33 or more lanes there, LEAF and SHADE hold at most 31 between them, so neither "nL > nT" nor "nS >= RTW_S_HI" (52) can be true
-            // and the scheduler would say TRAVERSE again -- the same decisions from one ballot instead of three, and without the register
-            // copies the compiler puts at the joins of the three-way branch for state that only LEAF and SHADE change (~16 v_mov per burst).
-            static_assert(RTW_S_HI > 31u && RTW_T_LO <= 33u, "the shortcut below assumes the thresholds of the scheduler");
-            uint32_t live = nT;
-            for (;;) {
-                // (the burst's census is summed in two scalars of its own and added once: kept in c_steps / c_lanes directly, the register
-                // allocator -- out of SGPRs in this kernel -- holds the totals in VGPRs and every visit paid a v_add for each)
-                uint32_t b_steps = 0, b_lanes = 0;
-                for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
-                    b_steps++; b_lanes += live;
-                    if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr); else trav_node(A.bvh, tr); }
-                    if (u + 1 >= RTW_TRAV_UNROLL) break;
-                    live = lanes_in(in_trav<stack_t>(tr.node));
-                    if (live == 0u) break;
+        } else {
+            bool burst = !run_leaf;
+            if (run_leaf) {
+                c_steps[1]++; c_lanes[1] += nL;
+                if (in_leaf<stack_t>(tr.node)) {
+                    const uint32_t s = leaf_sphere<stack_t>(tr.node);
+                    const f4 gs = geom_in_lds ? lgeom[s] : sc.geom[s];
+                    exact_sphere<MOVING>(gs, MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, tr.ra, a_plain, A.mint, A.maxt, tr.best, tr.best_t);
+                    tr.hi_lim = tr.best_t + tr.tau_t;
+                    trav_pop<stack_t>(tr);
                 }
-                asm volatile("" : "+s"(b_steps), "+s"(b_lanes));
-                c_steps[0] += b_steps; c_lanes[0] += b_lanes;
-#ifdef RTW_STAMP
-                break;                                       // (diagnostic build: every burst is timed as a trip of the outer loop)
-#else
-                if (live == 0u) break;
-                live = lanes_in(in_trav<stack_t>(tr.node));
-                if (live < 33u) break;
-                if (++trips > RTW_MAX_TRIPS) break;          // (the outer loop's valve fires on its next trip)
+#ifndef RTW_STAMP
+                // straight on to the bursts, without asking the scheduler, when more than half of the lanes are in TRAVERSE after the pops
+                // (the same shortcut, and the same argument, as between bursts)
+                nT = lanes_in(in_trav<stack_t>(tr.node)); burst = nT >= 33u;
 #endif
             }
-        } else {
-            c_steps[1]++; c_lanes[1] += nL;
-            if (in_leaf<stack_t>(tr.node)) {
-                const uint32_t s = leaf_sphere<stack_t>(tr.node);
-                const f4 gs = geom_in_lds ? lgeom[s] : sc.geom[s];
-                exact_sphere<MOVING>(gs, MOVING ? sc.vel[s] : f4{ 0, 0, 0, 0 }, s, pt.o, pt.d, pt.tm, tr.a, tr.ra, a_plain, A.mint, A.maxt, tr.best, tr.best_t);
-                tr.hi_lim = tr.best_t + tr.tau_t;
-                trav_pop<stack_t>(tr);
+            if (burst) {
+                // RTW_TRAV_UNROLL node visits per scheduling decision: the scheduler's ballots and branches are
+                // paid once per burst; lanes that leave TRAVERSE (leaf reached / query done) sit out the rest of it.
+                // Bursts follow one another without a trip through the scheduler while MORE THAN HALF of the lanes are still in TRAVERSE: with
+                // 33 or more lanes there, LEAF and SHADE hold at most 31 between them, so neither "nL > nT" nor "nS >= RTW_S_HI" (52) can be true
+                // and the scheduler would say TRAVERSE again -- the same decisions from one ballot instead of three, and without the register
+                // copies the compiler puts at the joins of the three-way branch for state that only LEAF and SHADE change (~16 v_mov per burst).
+                static_assert(RTW_S_HI > 31u && RTW_T_LO <= 33u, "the shortcut below assumes the thresholds of the scheduler");
+                uint32_t live = nT;
+                for (;;) {
+                    // (the burst's census is summed in two scalars of its own and added once: kept in c_steps / c_lanes directly, the register
+                    // allocator -- out of SGPRs in this kernel -- holds the totals in VGPRs and every visit paid a v_add for each)
+                    uint32_t b_steps = 0, b_lanes = 0;
+                    for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
+                        b_steps++; b_lanes += live;
+                        if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr); else trav_node(A.bvh, tr); }
+                        if (u + 1 >= RTW_TRAV_UNROLL) break;
+                        live = lanes_in(in_trav<stack_t>(tr.node));
+                        if (live == 0u) break;
+                    }
+                    asm volatile("" : "+s"(b_steps), "+s"(b_lanes));
+                    c_steps[0] += b_steps; c_lanes[0] += b_lanes;
+    #ifdef RTW_STAMP
+                    break;                                       // (diagnostic build: every burst is timed as a trip of the outer loop)
+    #else
+                    if (live == 0u) break;
+                    live = lanes_in(in_trav<stack_t>(tr.node));
+                    if (live < 33u) break;
+                    if (++trips > RTW_MAX_TRIPS) break;          // (the outer loop's valve fires on its next trip)
+    #endif
+                }
             }
         }
 #ifdef RTW_STAMP
