@@ -858,6 +858,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
         const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
         const int which = run_shade ? 2 : (run_leaf ? 1 : 0);
 #endif
+        bool burst = false;
         if (run_shade) {
             c_steps[2]++; c_lanes[2] += nS;
             // a. the closest-hit query this lane was waiting on is complete: scatter, or end the path
@@ -918,8 +919,11 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             // Wave-uniform and STICKY: lanes of this wave still test leaves of queries begun in earlier SHADE steps, so once any lane's d.d
             // has left [2^-20, 2^20] the wave stays on the generic sqrt / division (same bits, a few more instructions) for good.
             if (__ballot(a_odd) != 0ull) a_plain = false;
+#ifndef RTW_STAMP
+            nT = lanes_in(in_trav<stack_t>(tr.node)); burst = nT >= 33u;      // (as after a LEAF step)
+#endif
         } else {
-            bool burst = !run_leaf;
+            burst = !run_leaf;
             if (run_leaf) {
                 c_steps[1]++; c_lanes[1] += nL;
                 if (in_leaf<stack_t>(tr.node)) {
@@ -935,37 +939,37 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
                 nT = lanes_in(in_trav<stack_t>(tr.node)); burst = nT >= 33u;
 #endif
             }
-            if (burst) {
-                // RTW_TRAV_UNROLL node visits per scheduling decision: the scheduler's ballots and branches are
-                // paid once per burst; lanes that leave TRAVERSE (leaf reached / query done) sit out the rest of it.
-                // Bursts follow one another without a trip through the scheduler while MORE THAN HALF of the lanes are still in TRAVERSE: with
-                // 33 or more lanes there, LEAF and SHADE hold at most 31 between them, so neither "nL > nT" nor "nS >= RTW_S_HI" (52) can be true
-                // and the scheduler would say TRAVERSE again -- the same decisions from one ballot instead of three, and without the register
-                // copies the compiler puts at the joins of the three-way branch for state that only LEAF and SHADE change (~16 v_mov per burst).
-                static_assert(RTW_S_HI > 31u && RTW_T_LO <= 33u, "the shortcut below assumes the thresholds of the scheduler");
-                uint32_t live = nT;
-                for (;;) {
-                    // (the burst's census is summed in two scalars of its own and added once: kept in c_steps / c_lanes directly, the register
-                    // allocator -- out of SGPRs in this kernel -- holds the totals in VGPRs and every visit paid a v_add for each)
-                    uint32_t b_steps = 0, b_lanes = 0;
-                    for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
-                        b_steps++; b_lanes += live;
-                        if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr); else trav_node(A.bvh, tr); }
-                        if (u + 1 >= RTW_TRAV_UNROLL) break;
-                        live = lanes_in(in_trav<stack_t>(tr.node));
-                        if (live == 0u) break;
-                    }
-                    asm volatile("" : "+s"(b_steps), "+s"(b_lanes));
-                    c_steps[0] += b_steps; c_lanes[0] += b_lanes;
-    #ifdef RTW_STAMP
-                    break;                                       // (diagnostic build: every burst is timed as a trip of the outer loop)
-    #else
-                    if (live == 0u) break;
+        }
+        if (burst) {
+            // RTW_TRAV_UNROLL node visits per scheduling decision: the scheduler's ballots and branches are
+            // paid once per burst; lanes that leave TRAVERSE (leaf reached / query done) sit out the rest of it.
+            // Bursts follow one another without a trip through the scheduler while MORE THAN HALF of the lanes are still in TRAVERSE: with
+            // 33 or more lanes there, LEAF and SHADE hold at most 31 between them, so neither "nL > nT" nor "nS >= RTW_S_HI" (52) can be true
+            // and the scheduler would say TRAVERSE again -- the same decisions from one ballot instead of three, and without the register
+            // copies the compiler puts at the joins of the three-way branch for state that only LEAF and SHADE change (~16 v_mov per burst).
+            static_assert(RTW_S_HI > 31u && RTW_T_LO <= 33u, "the shortcut below assumes the thresholds of the scheduler");
+            uint32_t live = nT;
+            for (;;) {
+                // (the burst's census is summed in two scalars of its own and added once: kept in c_steps / c_lanes directly, the register
+                // allocator -- out of SGPRs in this kernel -- holds the totals in VGPRs and every visit paid a v_add for each)
+                uint32_t b_steps = 0, b_lanes = 0;
+                for (int u = 0; u < RTW_TRAV_UNROLL; u++) {
+                    b_steps++; b_lanes += live;
+                    if (in_trav<stack_t>(tr.node)) { if (LDSN) trav_node_lds((const u4 *)lnodes, tr); else trav_node(A.bvh, tr); }
+                    if (u + 1 >= RTW_TRAV_UNROLL) break;
                     live = lanes_in(in_trav<stack_t>(tr.node));
-                    if (live < 33u) break;
-                    if (++trips > RTW_MAX_TRIPS) break;          // (the outer loop's valve fires on its next trip)
-    #endif
+                    if (live == 0u) break;
                 }
+                asm volatile("" : "+s"(b_steps), "+s"(b_lanes));
+                c_steps[0] += b_steps; c_lanes[0] += b_lanes;
+#ifdef RTW_STAMP
+                break;                                       // (diagnostic build: every burst is timed as a trip of the outer loop)
+#else
+                if (live == 0u) break;
+                live = lanes_in(in_trav<stack_t>(tr.node));
+                if (live < 33u) break;
+                if (++trips > RTW_MAX_TRIPS) break;          // (the outer loop's valve fires on its next trip)
+#endif
             }
         }
 #ifdef RTW_STAMP
