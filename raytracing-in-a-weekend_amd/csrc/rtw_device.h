@@ -101,6 +101,24 @@ __device__ __forceinline__ float sphere_root(float b, float disc, float a, float
 }
 __device__ __forceinline__ bool in_range(float v, float lo, float hi) { const float a = __builtin_fabsf(v); return a >= lo && a <= hi; }
 
+// Diagnostic build (-DRTW_CENSUS): how many lanes are live in each sub-block of a SHADE step.  Per-lane counters (summed over the wave at
+// the end of the kernel): n[k] counts the lanes that executed block k, w[k] its wave-level executions (the first active lane counts).
+// The product build compiles none of it (RTW_CEN expands to nothing, the pointer parameters are null and fold away).
+enum { CEN_SHADING = 0, CEN_INFLIGHT, CEN_MISS, CEN_HIT, CEN_DIELECTRIC, CEN_SCHLICK, CEN_DIFFUSE, CEN_UV_TRIP, CEN_BANK, CEN_NEED_UNIT,
+       CEN_START_PATH, CEN_DISK_TRIP, CEN_TRAV_BEGIN, CEN_DEPTH_END, CEN_BIG_ROOT, CEN_COOP, CEN_N };
+struct Cen { uint32_t n[CEN_N], w[CEN_N]; };
+#ifdef RTW_CENSUS
+__device__ __forceinline__ void cen_count(Cen *cn, int k) {
+    if (!cn) return;
+    const unsigned long long m = __ballot(true);
+    cn->n[k]++;
+    cn->w[k] += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u ? 1u : 0u;
+}
+#define RTW_CEN(cn, k) cen_count(cn, k)
+#else
+#define RTW_CEN(cn, k) do { } while (0)
+#endif
+
 // unit(a) = a / sqrt(a.a) (vec3.rs:213), correctly rounded sqrt and divisions.  hipcc expands every IEEE f32 sqrt to 17 and every
 // IEEE division to 12 instructions; most of those only serve operands near the ends of the exponent range (pre-scaling,
 // v_div_scale / v_div_fmas / v_div_fixup, the zero / inf / NaN classes).  When every lane of the wave has all three components
@@ -159,9 +177,10 @@ __device__ __forceinline__ float rng_f32(Rng &r) { return rng_n24(r) * (1.0f / 1
 __device__ __forceinline__ float rng_sym(Rng &r) { return __builtin_fmaf(rng_n24(r), 1.0f / 8388608.0f, -1.0f); }
 __device__ __forceinline__ float rng_offset(Rng &r, float c) { return __builtin_fmaf(rng_n24(r), 1.0f / 16777216.0f, c); }
 // vec3.rs:228-239.  `strict` (RTW_FLAG_CPP_DIFFUSE): the C++ twin accepts |p|^2 < 1 (C++/src/vec3.cpp:28-34), Rust <= 1.
-__device__ __forceinline__ v3 random_unit_vec(Rng &r, bool strict = false) {
+__device__ __forceinline__ v3 random_unit_vec(Rng &r, bool strict = false, Cen *cn = nullptr) {
     v3 p;
     for (;;) {
+        RTW_CEN(cn, CEN_UV_TRIP);
         p.x = rng_sym(r);                  // xi * (max - min) + min
         p.y = rng_sym(r);
         p.z = rng_sym(r);
@@ -171,8 +190,9 @@ __device__ __forceinline__ v3 random_unit_vec(Rng &r, bool strict = false) {
     return unit(p);
 }
 // vec3.rs:240-254 (C++/headers/vec3.h:35-41 with `strict`)
-__device__ __forceinline__ void random_in_unit_disk(Rng &r, float &px, float &py, bool strict = false) {
+__device__ __forceinline__ void random_in_unit_disk(Rng &r, float &px, float &py, bool strict = false, Cen *cn = nullptr) {
     for (;;) {
+        RTW_CEN(cn, CEN_DISK_TRIP);
         px = rng_sym(r);                   // xi * 2.0 - 1.0
         py = rng_sym(r);
         const float l2 = px * px + py * py;
@@ -315,7 +335,7 @@ __device__ __forceinline__ MatP mat_params(const DevMat &d) {                   
 }
 // `ud` is unit(dir), computed by the caller (the sky of a missing lane needs the same expression: one copy for the wave).
 // `flags`: RTW_FLAG_CPP_* select the C++ twin's dialect (generic build only; a compile-time 0 elsewhere).
-__device__ __forceinline__ v3 on_hit(const MatP m, v3 point, v3 normal, v3 dir, v3 ud, Rng &rng, float &cos_theta, uint32_t flags) {
+__device__ __forceinline__ v3 on_hit(const MatP m, v3 point, v3 normal, v3 dir, v3 ud, Rng &rng, float &cos_theta, uint32_t flags, Cen *cn = nullptr) {
     const bool front = !(dot(dir, normal) > 0.0f);
     // Shared by both branches: unit(dir), and its mirror direction.  reflect(ud, -n) == reflect(ud, n)
     // bit for bit ((-n*2) * dot(ud,-n) == (n*2) * dot(ud,n): negation is exact and commutes with the
@@ -323,6 +343,7 @@ __device__ __forceinline__ v3 on_hit(const MatP m, v3 point, v3 normal, v3 dir, 
     const v3 refl = reflect(ud, normal);
     v3 next;
     if (m.opacity > 0.0f) {
+        RTW_CEN(cn, CEN_DIELECTRIC);
         const v3 n = front ? normal : -normal;
         const float ratio = front ? m.inv_ir : m.ir;
         float ct = dot(-ud, n);
@@ -332,7 +353,7 @@ __device__ __forceinline__ v3 on_hit(const MatP m, v3 point, v3 normal, v3 dir, 
         const float rfl = reflectance(ct, front ? m.r0_front : m.r0_back);
         bool do_reflect = cannot_refract;
         // xi drawn only when refraction is possible; never by the C++ twin (Schlick term commented out, C++/headers/materials.h:106)
-        if (!do_reflect && !(flags & RTW_FLAG_CPP_DIELECTRIC)) do_reflect = rfl > rng_f32(rng);
+        if (!do_reflect && !(flags & RTW_FLAG_CPP_DIELECTRIC)) { RTW_CEN(cn, CEN_SCHLICK); do_reflect = rfl > rng_f32(rng); }
         next = do_reflect ? refl : refract(ud, n, ratio);
         cos_theta = 0.0f;
     } else if (flags & RTW_FLAG_CPP_DIFFUSE) {
@@ -347,7 +368,8 @@ __device__ __forceinline__ v3 on_hit(const MatP m, v3 point, v3 normal, v3 dir, 
         if (__builtin_fabsf(next.x) < 1e-8f && __builtin_fabsf(next.y) < 1e-8f && __builtin_fabsf(next.z) < 1e-8f) next = normal;
         return next;
     } else {
-        const v3 target = normal + random_unit_vec(rng);      // drawn even for mirrors (materials.rs:142)
+        RTW_CEN(cn, CEN_DIFFUSE);
+        const v3 target = normal + random_unit_vec(rng, false, cn);      // drawn even for mirrors (materials.rs:142)
         const v3 sc = close_to_zero(target) ? normal : target;
         next = refl * m.metallicness + sc * (1.0f - m.metallicness);
         cos_theta = (m.metallicness != 1.0f) ? dot(sc, normal) : 0.0f;

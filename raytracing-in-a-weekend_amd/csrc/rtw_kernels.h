@@ -11,7 +11,7 @@
 #ifndef RTW_BLOCK
 #define RTW_BLOCK 256   // 4 waves per workgroup
 #endif
-#define RTW_N_STATS 32  // 64-bit counters a render launch accumulates (KArgs.stats)
+#define RTW_N_STATS 64  // 64-bit counters a render launch accumulates (KArgs.stats); [32..63] are used by the -DRTW_CENSUS diagnostic build only
 #ifndef RTW_LIST_WALK_MAX_DEFAULT
 #define RTW_LIST_WALK_MAX_DEFAULT 48u  // RTW_OPT_LIST_WALK_MAX: scenes this small walk the list even when the BVH is asked for (measured crossover ~56 spheres: profiles/r02_crossover.log)
 #endif

@@ -197,7 +197,8 @@ __device__ __forceinline__ RtwCamera load_camera() {
 }
 
 template <int SPEC>
-__device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path &pt) {
+__device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path &pt, Cen *cn = nullptr) {
+    RTW_CEN(cn, CEN_START_PATH);
     const RtwCamera cam = load_camera();
     const v3 cam_o = ld3(cam.origin), p00 = ld3(cam.pixel00), du = ld3(cam.delta_u), dv = ld3(cam.delta_v);
     pt.rng = rng_start(px.rng_base, px.s);
@@ -214,10 +215,10 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
             const uint32_t kx = px.s / A.s_root, ly = px.s % A.s_root;
             jx = ((float)px.i + ((float)kx + 0.5f) / (float)A.s_root) / (float)A.width;
             jy = ((float)px.j + ((float)ly + 0.5f) / (float)A.s_root) / (float)A.height;
-            random_in_unit_disk(pt.rng, rx, ry);
+            random_in_unit_disk(pt.rng, rx, ry, false, cn);
             o = cam_o + mk(rx, ry, 0.0f) * cam.lens_radius;
         } else {
-            random_in_unit_disk(pt.rng, rx, ry, !SPEC && (A.flags & RTW_FLAG_CPP_DIFFUSE));   // always drawn (viewport.rs:288)
+            random_in_unit_disk(pt.rng, rx, ry, !SPEC && (A.flags & RTW_FLAG_CPP_DIFFUSE), cn);   // always drawn (viewport.rs:288)
             o = cam_o + (ld3(cam.u) * rx + ld3(cam.v) * ry) * cam.lens_radius;
             if (samp<SPEC>(A) == RTW_SAMPLER_ROW) {              // viewport.rs:290-297
                 jx = rng_offset(pt.rng, (float)px.i);
@@ -250,7 +251,7 @@ __device__ __forceinline__ void shade_miss(const KArgs &A, Path &pt, v3 ud) {
 // One step of ray_color_* at the closest hit, given as the reference's `Hit` (objects.rs:16-23): point, normal,
 // col_mod, material.  Returns true when the path is finished (pt.L is then its radiance).
 template <int SPEC>
-__device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 ud, v3 point, v3 normal, v3 cm, MatP mat, v3 emitted) {
+__device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 ud, v3 point, v3 normal, v3 cm, MatP mat, v3 emitted, Cen *cn = nullptr) {
     if (integ<SPEC>(A) == RTW_INTEGRATOR_NORMAL) {             // C++/src/tests.cpp:91
         pt.L = mk(normal.x + 1.0f, normal.y + 1.0f, normal.z + 1.0f) * 0.5f;
         return true;
@@ -269,7 +270,7 @@ __device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 ud, v
         return false;
     }
     float cos_theta;
-    const v3 nd = on_hit(mat, point, normal, pt.d, ud, pt.rng, cos_theta, SPEC ? 0u : A.flags);
+    const v3 nd = on_hit(mat, point, normal, pt.d, ud, pt.rng, cos_theta, SPEC ? 0u : A.flags, cn);
     if (integ<SPEC>(A) == RTW_INTEGRATOR_BG_COLOR) {           // ray_color.rs:64-88, front-to-back
         // lambertian_scatter_pdf (materials.rs:5-13); pdf == 0 makes the reference's `color * pdf / pdf` a 0/0
         const float pdf = cos_theta > 0.0f ? cos_theta * 0.318309886183790671538f : 0.0f;
@@ -280,6 +281,7 @@ __device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 ud, v
     pt.o = point; pt.d = nd;
     pt.k++;
     if (pt.k >= A.depth) {                                   // depth exhausted: the innermost call returns black
+        RTW_CEN(cn, CEN_DEPTH_END);
         if (integ<SPEC>(A) != RTW_INTEGRATOR_BG_COLOR) pt.L = mk(0, 0, 0);
         return true;
     }
@@ -288,7 +290,8 @@ __device__ __forceinline__ bool shade_surface(const KArgs &A, Path &pt, v3 ud, v
 
 // ... at top-level sphere `best` (Sphere::collision_normal's Hit, sphere.rs:124-146).
 template <bool MOVING, int SPEC>
-__device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, v3 ud, int best, float best_t) {
+__device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, v3 ud, int best, float best_t, Cen *cn = nullptr) {
+    RTW_CEN(cn, CEN_HIT);
     const DevScene &sc = A.sc;
     f4 g = sc.geom[best];
     v3 c = mk(g.x, g.y, g.z);
@@ -297,16 +300,17 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, v3 ud, int b
     const v3 normal = unit(point - c);                       // sphere.rs:127
     const DevMat mat = sc.mat[best];
     const v3 cm = (SPEC == 1 || SPEC == 3) ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
-    return shade_surface<SPEC>(A, pt, ud, point, normal, cm, mat_params(mat), ld3(mat.emitted));
+    return shade_surface<SPEC>(A, pt, ud, point, normal, cm, mat_params(mat), ld3(mat.emitted), cn);
 }
 
 template <bool MOVING, int SPEC>
-__device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float best_t) {
+__device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float best_t, Cen *cn = nullptr) {
+    RTW_CEN(cn, CEN_INFLIGHT);
     // unit(direction) feeds the scatter of the lanes that hit (materials.rs:111,143) and the sky of the lanes that missed
     // (ray_color.rs:38): computed once, ahead of the divergent branches, instead of once in each
     const v3 ud = unit(pt.d);
-    if (best < 0) { shade_miss<SPEC>(A, pt, ud); return true; }
-    return shade_hit<MOVING, SPEC>(A, pt, ud, best, best_t);
+    if (best < 0) { RTW_CEN(cn, CEN_MISS); shade_miss<SPEC>(A, pt, ud); return true; }
+    return shade_hit<MOVING, SPEC>(A, pt, ud, best, best_t, cn);
 }
 
 // Scenes with quads / instances (generic build only): finish Scene::collision_normal (viewport.rs:136-150) for
@@ -324,7 +328,8 @@ __device__ __forceinline__ bool shade_geom(const KArgs &A, Path &pt, int best, f
 // A path ended: bank its radiance in the sample buffer (the resolve kernel adds the samples of a pixel
 // in sample order, viewport.rs:299).  Returns true when the unit is done.
 template <int SPEC>
-__device__ __forceinline__ bool finish_path(const KArgs &A, Pixel &px, Path &pt) {
+__device__ __forceinline__ bool finish_path(const KArgs &A, Pixel &px, Path &pt, Cen *cn = nullptr) {
+    RTW_CEN(cn, CEN_BANK);
     if (pt.poison) { const float qn = __builtin_nanf(""); pt.L = mk(qn, qn, qn); }
     float3 *dst = reinterpret_cast<float3 *>(A.samples + 3 * (size_t)px.slot);
     if (SPEC == 3 || (SPEC == 0 && (A.flags & RTW_FLAG_CHUNK_SUMS))) {        // one slot per unit, the unit's samples added into it in sample order
@@ -600,7 +605,8 @@ __device__ __forceinline__ BvhBegin load_bvh_begin() {
 }
 
 template <bool MOVING, class S>
-__device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav &tr, uint32_t sp0, bool a_plain_wave, bool &a_odd) {
+__device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav &tr, uint32_t sp0, bool a_plain_wave, bool &a_odd, Cen *cn = nullptr) {
+    RTW_CEN(cn, CEN_TRAV_BEGIN);
     const BvhBegin bv = load_bvh_begin();
     const v3 o = pt.o, d = pt.d;
     tr.a = dot(d, d);
@@ -835,6 +841,12 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
     unsigned long long c_time[3] = { 0, 0, 0 };
     unsigned long long sub[5] = { 0, 0, 0, 0, 0 }, t_sub = 0;     // SHADE: hit / bank + next unit / camera ray / query begin / rest
 #endif
+#ifdef RTW_CENSUS
+    Cen cen_store; for (int k = 0; k < CEN_N; k++) cen_store.n[k] = cen_store.w[k] = 0u;
+    Cen *const cn = &cen_store;
+#else
+    Cen *const cn = nullptr;
+#endif
 
 #ifdef RTW_ENDTIMES
     const unsigned long long t_wave_start = __builtin_amdgcn_s_memtime();
@@ -869,16 +881,18 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             t_sub = t_begin;
 #endif
             if (shading) {
+                RTW_CEN(cn, CEN_SHADING);
                 if (fl & F_INFLIGHT) {
                     fl &= ~F_INFLIGHT;
-                    const bool done = GEOM ? shade_geom<MOVING>(A, pt, tr.best, tr.best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t);
+                    const bool done = GEOM ? shade_geom<MOVING>(A, pt, tr.best, tr.best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t, cn);
                     if (done) fl |= F_DONE;
                 }
             }
             RTW_SUB_STAMP(0);
             if (shading) {
-                if (fl & F_DONE) { fl &= ~F_DONE; if (finish_path<SPEC>(A, px, pt)) fl &= ~F_HAVE; else fl |= F_NEWPATH; }
+                if (fl & F_DONE) { fl &= ~F_DONE; if (finish_path<SPEC>(A, px, pt, cn)) fl &= ~F_HAVE; else fl |= F_NEWPATH; }
                 need_unit = (fl & F_HAVE) == 0u;
+                if (need_unit) RTW_CEN(cn, CEN_NEED_UNIT);
             }
             // b. next work unit.  Executed by EVERY lane of the wave (not only the ones in SHADE): the wave's
             //    reserve must stay wave-uniform, which it only does if all lanes run its bookkeeping.
@@ -903,13 +917,13 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
                 if (exhausted) tr.node = (int)Code<stack_t>::DEAD;
                 if (fl & F_HAVE) {
                     // c. next camera ray (a lane whose path continues keeps its scattered ray)
-                    if (fl & F_NEWPATH) { fl &= ~F_NEWPATH; start_path<SPEC>(A, px, pt); started = true; }
+                    if (fl & F_NEWPATH) { fl &= ~F_NEWPATH; start_path<SPEC>(A, px, pt, cn); started = true; }
                     // d. start the next closest-hit query
                     if (!SPEC && A.depth == 0 && A.integrator != RTW_INTEGRATOR_NORMAL) {   // `if depth < 1 { return black }` (ray_color.rs:14-16)
                         pt.L = A.integrator == RTW_INTEGRATOR_RUST2 ? ld3(A.bg) : mk(0, 0, 0);
                         fl |= F_DONE;                                      // banked on the next SHADE trip
                     } else {
-                        trav_begin<MOVING, stack_t>(A, pt, tr, lds_addr(lds_raw) + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t), a_plain, a_odd);
+                        trav_begin<MOVING, stack_t>(A, pt, tr, lds_addr(lds_raw) + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t), a_plain, a_odd, cn);
                         fl |= F_INFLIGHT;
                     }
                 }
@@ -979,6 +993,13 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
 #endif
     }
     if (GEOM) { flush_quads(A, n_quad); flush_tests(A, n_isph); }
+#ifdef RTW_CENSUS
+    for (int k = 0; k < CEN_N; k++) {          // diagnostic build: stats[32 + 2k] = wave-level executions of sub-block k, [33 + 2k] = lanes live in them
+        unsigned long long w = cn->w[k], n = cn->n[k];
+        for (int off = 32; off > 0; off >>= 1) { w += __shfl_down(w, off); n += __shfl_down(n, off); }
+        if ((threadIdx.x & 63u) == 0) { atomicAdd(&A.stats[32 + 2 * k], w); atomicAdd(&A.stats[33 + 2 * k], n); }
+    }
+#endif
     if ((threadIdx.x & 63u) == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)w_rays);
         atomicAdd(&A.stats[1], (unsigned long long)w_seg);

@@ -611,6 +611,19 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
         stats->kernel_ms = ms;
         for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
         for (int k = 3; k < 5; k++) { stats->phase_steps[k] = h_stats[16 + 2 * (k - 3)]; stats->phase_lanes[k] = h_stats[17 + 2 * (k - 3)]; }
+#ifdef RTW_CENSUS                                   // diagnostic build only (scripts/gpu_census.py): lanes live in the sub-blocks of a SHADE step
+        if (getenv("RTW_CENSUS_DUMP")) {
+            static const char *names[CEN_N] = { "shading", "inflight (unit(d))", "miss (sky)", "hit (point, normal, material)", "dielectric branch", "schlick draw",
+                                                "diffuse branch", "unit-vector loop trip", "bank store", "needs a work unit", "start_path", "lens-disk loop trip",
+                                                "trav_begin", "depth exhausted", "-", "cooperative round" };
+            std::fprintf(stderr, "rtw census: %llu SHADE steps\n", h_stats[7]);
+            for (int k = 0; k < CEN_N; k++)
+                if (h_stats[32 + 2 * k])
+                    std::fprintf(stderr, "rtw census: %-32s executions %12llu (%.3f per SHADE step)  lanes %14llu  live fraction %.4f  lanes per SHADE step %.2f\n", names[k],
+                                 h_stats[32 + 2 * k], (double)h_stats[32 + 2 * k] / (double)h_stats[7], h_stats[33 + 2 * k],
+                                 (double)h_stats[33 + 2 * k] / (64.0 * (double)h_stats[32 + 2 * k]), (double)h_stats[33 + 2 * k] / (double)h_stats[7]);
+        }
+#endif
 #if defined(RTW_STAMP) || defined(RTW_ENDTIMES)     // diagnostic builds only (scripts/gpu_endtimes.py)
         if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu   of shade: hit %llu, bank + next unit %llu, camera ray %llu, query begin %llu\n",
                                                    h_stats[11], h_stats[12], h_stats[13], h_stats[16], h_stats[17], h_stats[18], h_stats[19]);
