@@ -200,6 +200,37 @@ __device__ __forceinline__ void random_in_unit_disk(Rng &r, float &px, float &py
     }
 }
 
+// Both rejection samplers of a SHADE step in ONE loop (specialised builds).  In a SHADE step the lanes whose ray hit a non-dielectric
+// sphere need random_unit_vec (vec3.rs:228-239: three draws per candidate) and the lanes that start a new path need random_in_unit_disk
+// (vec3.rs:240-254: two draws per candidate) -- different lanes, the same instructions.  Run one after the other the two loops cost
+// 5.55 + 2.76 trips per step at 0.16 / 0.15 live lanes (profiles/r03_census_baseline.txt); as one loop the disk lanes ride along in the
+// trips the ball lanes need anyway.  A disk lane's third draw is switched off by per-lane constants rather than by an exec-mask region:
+// its LCG step multiplies by 1 and adds 0 (the state stays), its z is fma(n, 0, 0) = +0, and (x*x + y*y) + 0 has the bits of x*x + y*y.
+// Every lane consumes exactly the draws the reference's loops consume, in their order.  `ball`: this lane wants a point of the unit
+// ball (else of the unit disk); only lanes with `need` enter.
+__device__ __forceinline__ void sample_ball_or_disk(Rng &r, bool need, bool ball, float &x, float &y, float &z, Cen *cn = nullptr) {
+    if (need) {
+        const uint32_t am = ball ? 747796405U : 1U, ai = ball ? r.inc : 0U;
+        const float kz = ball ? (1.0f / 8388608.0f) : 0.0f, oz = ball ? -1.0f : 0.0f;
+#ifdef RTW_EXPERIMENT_CAP_TRIPS
+        int trip = 0;
+#endif
+        for (;;) {
+            RTW_CEN(cn, CEN_UV_TRIP);
+            x = rng_sym(r);
+            y = rng_sym(r);
+            const uint32_t old = r.state;
+            r.state = old * am + ai;
+            z = __builtin_fmaf((float)(old >> 8), kz, oz);
+            const float l2 = x * x + y * y + z * z;
+            if (l2 <= 1.0f) break;
+#ifdef RTW_EXPERIMENT_CAP_TRIPS      /* WRONG IMAGES: an upper bound on what any scheme that shortens the loop's tail can gain (profiles/r03_ab_coop_bound.log) */
+            if (++trip >= RTW_EXPERIMENT_CAP_TRIPS) { const float s = 0.5f * __builtin_amdgcn_rsqf(l2); x *= s; y *= s; z *= s; break; }
+#endif
+        }
+    }
+}
+
 // ---- device scene ------------------------------------------------------------------------------
 // Hot, wave-uniform stream (scalar loads):  geom[i] = {cx, cy, cz, r*r},  vel[i] = {vx, vy, vz, 0}.
 // Cold, per-lane record fetched only for the sphere a lane hit:
@@ -374,6 +405,40 @@ __device__ __forceinline__ v3 on_hit(const MatP m, v3 point, v3 normal, v3 dir, 
         next = refl * m.metallicness + sc * (1.0f - m.metallicness);
         cos_theta = (m.metallicness != 1.0f) ? dot(sc, normal) : 0.0f;
     }
+    if (close_to_zero(next)) next = front ? normal : normal * -1.0f;
+    return next;
+}
+
+// Material::on_hit in two halves around the merged rejection loop (specialised builds: Rust dialect, gradient integrator).
+// First half: everything up to the random unit vector.  A dielectric lane is complete after it (returns true, `next` is its direction); a
+// diffuse / metallic lane gets its mirror direction in `next` and waits for its unit vector.
+__device__ __forceinline__ bool on_hit_first(const MatP m, v3 normal, v3 dir, v3 ud, Rng &rng, v3 &next, bool &front, Cen *cn = nullptr) {
+    front = !(dot(dir, normal) > 0.0f);
+    const v3 refl = reflect(ud, normal);          // (shared by both branches: see on_hit)
+    if (m.opacity > 0.0f) {
+        RTW_CEN(cn, CEN_DIELECTRIC);
+        const v3 n = front ? normal : -normal;
+        const float ratio = front ? m.inv_ir : m.ir;
+        float ct = dot(-ud, n);
+        if (ct > 1.0f) ct = 1.0f;
+        const float st = sqrt_ieee(1.0f - ct * ct);
+        const bool cannot_refract = ratio * st > 1.0f;
+        const float rfl = reflectance(ct, front ? m.r0_front : m.r0_back);
+        bool do_reflect = cannot_refract;
+        if (!do_reflect) { RTW_CEN(cn, CEN_SCHLICK); do_reflect = rfl > rng_f32(rng); }
+        next = do_reflect ? refl : refract(ud, n, ratio);
+        if (close_to_zero(next)) next = front ? normal : normal * -1.0f;
+        return true;
+    }
+    RTW_CEN(cn, CEN_DIFFUSE);
+    next = refl;
+    return false;
+}
+// Second half: `p` is the accepted point of the unit ball (sample_ball_or_disk), `refl` the mirror direction of the first half.
+__device__ __forceinline__ v3 on_hit_second(float metallicness, v3 normal, v3 refl, bool front, v3 p) {
+    const v3 target = normal + unit(p);               // random_unit_vec = unit(accepted point) (vec3.rs:238)
+    const v3 sc = close_to_zero(target) ? normal : target;
+    v3 next = refl * metallicness + sc * (1.0f - metallicness);
     if (close_to_zero(next)) next = front ? normal : normal * -1.0f;
     return next;
 }

@@ -313,6 +313,72 @@ __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float 
     return shade_hit<MOVING, SPEC>(A, pt, ud, best, best_t, cn);
 }
 
+// ---- specialised builds: a SHADE step in two halves around ONE rejection loop (sample_ball_or_disk, rtw_device.h) -------------------------
+// First half of shade<>() for the gradient integrator: miss -> sky; hit -> point, normal, material and Material::on_hit up to its random
+// unit vector.  Returns true when the path is finished.  Otherwise pt.o / pt.thr / pt.k are final; pt.d is final for a dielectric hit, and
+// for a diffuse / metallic one (need_ball) it holds the mirror direction until on_hit_second() has the unit vector (nrm, metal, front: what
+// that half needs of the hit).  A lane whose depth is exhausted needs no scatter direction at all: it is finished here.
+template <bool MOVING, int SPEC>
+__device__ __forceinline__ bool shade_first(const KArgs &A, Path &pt, int best, float best_t, bool &need_ball, v3 &nrm, float &metal, bool &front, Cen *cn = nullptr) {
+    RTW_CEN(cn, CEN_INFLIGHT);
+    const v3 ud = unit(pt.d);
+    if (best < 0) { RTW_CEN(cn, CEN_MISS); shade_miss<SPEC>(A, pt, ud); return true; }
+    RTW_CEN(cn, CEN_HIT);
+    const DevScene &sc = A.sc;
+    f4 g = sc.geom[best];
+    v3 c = mk(g.x, g.y, g.z);
+    if (MOVING) { f4 vv = sc.vel[best]; c = c + mk(vv.x, vv.y, vv.z) * pt.tm; }
+    const v3 point = pt.o + pt.d * best_t;                   // r.at(x)
+    const v3 normal = unit(point - c);                       // sphere.rs:127
+    const DevMat mat = sc.mat[best];
+    const v3 cm = (SPEC == 1 || SPEC == 3) ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
+    v3 next; bool fr;
+    const bool complete = on_hit_first(mat_params(mat), normal, pt.d, ud, pt.rng, next, fr, cn);
+    pt.thr = pt.thr * cm;
+    pt.o = point; pt.d = next;
+    pt.k++;
+    if (pt.k >= A.depth) { RTW_CEN(cn, CEN_DEPTH_END); pt.L = mk(0, 0, 0); return true; }      // depth exhausted: the innermost call returns black
+    need_ball = !complete; nrm = normal; metal = mat.metallicness; front = fr;
+    return false;
+}
+
+// ... the same from the hit on, for a lane whose unit(direction) `ud` the caller already has (and which is known not to end here).
+template <bool MOVING, int SPEC>
+__device__ __forceinline__ void shade_hit_first(const KArgs &A, Path &pt, v3 ud, int best, float best_t, bool &need_ball, v3 &nrm, float &metal, bool &front, Cen *cn = nullptr) {
+    RTW_CEN(cn, CEN_HIT);
+    const DevScene &sc = A.sc;
+    f4 g = sc.geom[best];
+    v3 c = mk(g.x, g.y, g.z);
+    if (MOVING) { f4 vv = sc.vel[best]; c = c + mk(vv.x, vv.y, vv.z) * pt.tm; }
+    const v3 point = pt.o + pt.d * best_t;                   // r.at(x)
+    const v3 normal = unit(point - c);                       // sphere.rs:127
+    const DevMat mat = sc.mat[best];
+    const v3 cm = (SPEC == 1 || SPEC == 3) ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
+    v3 next; bool fr;
+    const bool complete = on_hit_first(mat_params(mat), normal, pt.d, ud, pt.rng, next, fr, cn);
+    pt.thr = pt.thr * cm;
+    pt.o = point; pt.d = next;
+    pt.k++;
+    need_ball = !complete; nrm = normal; metal = mat.metallicness; front = fr;
+}
+
+// start_path<>() for the render_row sampler (viewport.rs:286-297), in two halves around the lens-disk draw.
+__device__ __forceinline__ void start_path_first(const Pixel &px, Path &pt, Cen *cn = nullptr) {
+    RTW_CEN(cn, CEN_START_PATH);
+    pt.rng = rng_start(px.rng_base, px.s);
+    pt.thr = mk(1.0f, 1.0f, 1.0f); pt.L = mk(0, 0, 0); pt.poison = false; pt.k = 0;
+}
+__device__ __forceinline__ void start_path_second(const Pixel &px, Path &pt, float rx, float ry) {
+    const RtwCamera cam = load_camera();
+    const v3 cam_o = ld3(cam.origin), p00 = ld3(cam.pixel00), du = ld3(cam.delta_u), dv = ld3(cam.delta_v);
+    const v3 o = cam_o + (ld3(cam.u) * rx + ld3(cam.v) * ry) * cam.lens_radius;       // viewport.rs:288-289
+    const float jx = rng_offset(pt.rng, (float)px.i);                               // viewport.rs:290-297
+    const float jy = rng_offset(pt.rng, (float)px.j);
+    const float tm = cam.time0 + cam.shutter * rng_f32(pt.rng);
+    const v3 d = (p00 + du * jx) + dv * jy;
+    pt.o = o; pt.d = d; pt.tm = tm;
+}
+
 // Scenes with quads / instances (generic build only): finish Scene::collision_normal (viewport.rs:136-150) for
 // the query whose sphere part returned (best, best_t), then shade whichever object won.
 template <bool MOVING>
@@ -880,6 +946,83 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
 #ifdef RTW_STAMP
             t_sub = t_begin;
 #endif
+            if constexpr (SPEC != 0 && !GEOM) {
+            // ---- specialised builds: the step in two halves around one rejection loop for the scatter directions AND the lens samples ----
+            bool need_ball = false, need_disk = false, front = false;
+#ifndef RTW_SHADE_ORDER
+#define RTW_SHADE_ORDER 2
+#endif
+#if RTW_SHADE_ORDER == 1
+#ifdef RTW_SHADE_ZINIT
+            v3 nrm = mk(0, 0, 0); float metal = 0.0f;
+#else
+            v3 nrm; float metal;
+#endif
+            if (shading) {
+                RTW_CEN(cn, CEN_SHADING);
+                // a. the closest-hit query this lane was waiting on is complete: sky, or the hit up to its random unit vector
+                if (fl & F_INFLIGHT) {
+                    fl &= ~F_INFLIGHT;
+                    if (shade_first<MOVING, SPEC>(A, pt, tr.best, tr.best_t, need_ball, nrm, metal, front, cn)) fl |= F_DONE;
+                }
+            }
+#else
+            // a. the closest-hit query this lane was waiting on is complete.  Paths that END here -- the ray missed (sky), or its depth is
+            //    exhausted (black) -- are finished first, so that their lanes' next camera rays and the hits' scatter directions meet in ONE
+            //    rejection loop further down; the lanes that hit keep unit(direction) until then.
+            v3 nrm, ud; float metal;
+            bool hit = false;
+            if (shading) {
+                RTW_CEN(cn, CEN_SHADING);
+                if (fl & F_INFLIGHT) {
+                    fl &= ~F_INFLIGHT;
+                    RTW_CEN(cn, CEN_INFLIGHT);
+                    ud = unit(pt.d);
+                    if (tr.best < 0) { RTW_CEN(cn, CEN_MISS); shade_miss<SPEC>(A, pt, ud); fl |= F_DONE; }
+                    else if (pt.k + 1u >= A.depth) { RTW_CEN(cn, CEN_DEPTH_END); pt.L = mk(0, 0, 0); fl |= F_DONE; }   // depth exhausted: the innermost call returns black
+                    else hit = true;
+                }
+            }
+#endif
+            RTW_SUB_STAMP(0);
+            if (shading) {
+                if (fl & F_DONE) { fl &= ~F_DONE; if (finish_path<SPEC>(A, px, pt, cn)) fl &= ~F_HAVE; else fl |= F_NEWPATH; }
+                need_unit = (fl & F_HAVE) == 0u;
+                if (need_unit) RTW_CEN(cn, CEN_NEED_UNIT);
+            }
+            // b. next work unit (every lane of the wave: the reserve stays wave-uniform; see the generic path below)
+            bool exhausted = false;
+            const bool got = fetch_pixel(A, need_unit, px, exhausted, rs);
+            if (__ballot(exhausted) != 0ull) t_lo = RTW_T_LO_DRAIN;
+            RTW_SUB_STAMP(1);
+            if (shading) {
+                if (got) fl |= F_HAVE | F_NEWPATH;
+                if (exhausted) tr.node = (int)Code<stack_t>::DEAD;
+                // c. next camera ray, up to its lens sample
+                if ((fl & F_HAVE) && (fl & F_NEWPATH)) { fl &= ~F_NEWPATH; start_path_first(px, pt, cn); need_disk = true; started = true; }
+            }
+#if RTW_SHADE_ORDER != 1
+            //    ... the hit, up to its random unit vector
+            if (hit) shade_hit_first<MOVING, SPEC>(A, pt, ud, tr.best, tr.best_t, need_ball, nrm, metal, front, cn);
+#endif
+            // d. ONE rejection loop: points of the unit ball for the lanes that scatter, of the unit disk for the lanes that start a path
+#ifdef RTW_SHADE_ZINIT
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+#else
+            float sx, sy, sz;
+#endif
+            sample_ball_or_disk(pt.rng, need_ball || need_disk, need_ball, sx, sy, sz, cn);
+            if (need_ball) pt.d = on_hit_second(metal, nrm, pt.d, front, mk(sx, sy, sz));
+            if (need_disk) start_path_second(px, pt, sx, sy);
+            RTW_SUB_STAMP(2);
+            // e. start the next closest-hit query
+            if (shading && (fl & F_HAVE)) {
+                trav_begin<MOVING, stack_t>(A, pt, tr, lds_addr(lds_raw) + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t), a_plain, a_odd, cn);
+                fl |= F_INFLIGHT;
+            }
+            RTW_SUB_STAMP(3);
+            } else {
+            // ---- generic build (every integrator / sampler / dialect, quads and instances) ----
             if (shading) {
                 RTW_CEN(cn, CEN_SHADING);
                 if (fl & F_INFLIGHT) {
@@ -929,6 +1072,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
                 }
             }
             RTW_SUB_STAMP(3);
+            }
             w_rays += (uint32_t)__popcll(__ballot(started));
             // Wave-uniform and STICKY: lanes of this wave still test leaves of queries begun in earlier SHADE steps, so once any lane's d.d
             // has left [2^-20, 2^20] the wave stays on the generic sqrt / division (same bits, a few more instructions) for good.
