@@ -168,7 +168,7 @@ typedef struct RtwScene {
 } RtwScene;
 
 typedef struct RtwParams {
-    uint32_t width, height;       /* full image */
+    uint32_t width, height;       /* full image; each at most 65535 (RTW_E_INVALID beyond) */
     uint32_t samples;             /* Viewport.samples (see sampler for the count actually traced) */
     uint32_t depth;               /* Viewport.depth: max closest-hit queries per camera ray       */
     float    gamma;               /* output = powf(mean, 1/gamma) (viewport.rs:207-213)           */
@@ -262,7 +262,7 @@ int  rtw_render(const RtwCamera *cam, const RtwScene *scene, const RtwParams *pa
 
 /* Tuning knobs of a context (they were process environment variables up to ABI v2).  None of them changes the image. */
 enum {
-    RTW_OPT_CHUNK_LEN        = 1, /* samples per work unit, 1..4096; 0 = chosen from the size of the launch (default)          */
+    RTW_OPT_CHUNK_LEN        = 1, /* samples per work unit, 1..255; 0 = chosen from the size of the launch (default)           */
     RTW_OPT_SAMPLE_BANK_GB   = 2, /* budget of the per-sample radiance bank in GiB (default 48); larger frames are
                                      rendered in bands of tile rows, a budget below one tile row fails with RTW_E_NOMEM  */
     RTW_OPT_LDS_GEOM         = 3, /* sphere {centre, r^2} in LDS next to the f16 nodes: -1 auto (default), 0 off, 1 on   */

@@ -50,12 +50,18 @@ namespace rtw {
 template <int SPEC> __device__ __forceinline__ uint32_t integ(const KArgs &A) { return SPEC ? (uint32_t)RTW_INTEGRATOR_GRADIENT : A.integrator; }
 template <int SPEC> __device__ __forceinline__ uint32_t samp(const KArgs &A) { return SPEC ? (uint32_t)RTW_SAMPLER_ROW : A.sampler; }
 
-struct Pixel {            // the work unit a lane owns: a run of consecutive samples of one pixel
-    uint32_t i, j;        // column, image row
+struct Pixel {            // the work unit a lane owns: a run of consecutive samples of one pixel.  Four registers (they live through every step of
+                          // the persistent loop, and the specialised builds have 72): the shim keeps width, height < 2^16, samples < 2^24, units <= 255 samples
+    uint32_t ij;          // column | image row << 16
     uint32_t rng_base;    // hash of (seed, pixel)
-    uint32_t s, s_end;    // next sample index, one past the last of this unit
+    uint32_t s;           // next sample index | samples of this unit still to trace (this one included) << 24
     uint32_t slot;        // where sample s goes in KArgs.samples (advances with s)
 };
+__device__ __forceinline__ uint32_t px_i(const Pixel &px) { return px.ij & 0xFFFFu; }
+__device__ __forceinline__ uint32_t px_j(const Pixel &px) { return px.ij >> 16; }
+__device__ __forceinline__ uint32_t px_s(const Pixel &px) { return px.s & 0xFFFFFFu; }
+// the unit's next sample; true when that was its last
+__device__ __forceinline__ bool px_advance(Pixel &px) { px.s += 1u - (1u << 24); return px.s < (1u << 24); }
 
 struct Path {             // the path a lane is tracing
     v3 o, d;              // current ray
@@ -158,21 +164,21 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
     if (avail == 0u) { exhausted = true; return false; }          // the queue is empty
     if (rank >= avail) return false;                              // reserve ran out: next trip refills
     const uint32_t p = w & 63u;                                    // pixel of the tile
-    px.i = rs.i0 + (p & 7u);
+    const uint32_t i = rs.i0 + (p & 7u);
     const uint32_t k = rs.k0 + (p >> 3);                           // compact row of this partition
-    if (!(px.i < A.width && k < A.k_end)) return false;            // padding item: ask again next trip
-    px.j = k;   // compact row -> image row (RtwParams row partition)
+    if (!(i < A.width && k < A.k_end)) return false;               // padding item: ask again next trip
+    uint32_t j = k;   // compact row -> image row (RtwParams row partition)
     if (A.part_count > 1) {
         // tiles are 8 rows tall and start on a multiple of 8, so with the usual 8-row blocks the block index is uniform too
-        if (A.row_block == 8u) px.j = ((rs.k0 >> 3) * A.part_count + A.part_index) * 8u + (p >> 3);
-        else px.j = ((k / A.row_block) * A.part_count + A.part_index) * A.row_block + (k % A.row_block);
+        if (A.row_block == 8u) j = ((rs.k0 >> 3) * A.part_count + A.part_index) * 8u + (p >> 3);
+        else j = ((k / A.row_block) * A.part_count + A.part_index) * A.row_block + (k % A.row_block);
     }
-    px.rng_base = rng_pixel_base(A.seed_lo, A.seed_hi, px.j * A.width + px.i);
-    px.s = rs.s0;
-    px.s_end = rs.s1;
+    px.ij = i | (j << 16);
+    px.rng_base = rng_pixel_base(A.seed_lo, A.seed_hi, j * A.width + i);
+    px.s = rs.s0 | ((rs.s1 - rs.s0) << 24);
     px.slot = rs.unit * 64u * A.bank_len + (w & 63u);            // [unit][sample of chunk][pixel of tile]: lanes that finish the same
                                                                    // sample of neighbouring pixels together fill whole sectors
-    return px.s < px.s_end;
+    return rs.s0 < rs.s1;
 }
 
 // Camera ray of sample px.s (the sampler loops of viewport.rs / Rust2 viewport.rs).
@@ -201,33 +207,33 @@ __device__ __forceinline__ void start_path(const KArgs &A, const Pixel &px, Path
     RTW_CEN(cn, CEN_START_PATH);
     const RtwCamera cam = load_camera();
     const v3 cam_o = ld3(cam.origin), p00 = ld3(cam.pixel00), du = ld3(cam.delta_u), dv = ld3(cam.delta_v);
-    pt.rng = rng_start(px.rng_base, px.s);
+    pt.rng = rng_start(px.rng_base, px_s(px));
     pt.thr = mk(1.0f, 1.0f, 1.0f); pt.L = mk(0, 0, 0); pt.poison = false; pt.k = 0;
     // (single assignment of pt.o / pt.d / pt.tm at the end: stores to different members on different
     //  branches get "sunk" into a phi of pointers by the optimiser, which forces the path state into scratch)
     v3 o, d; float tm = 0.0f;
     if (samp<SPEC>(A) == RTW_SAMPLER_NO_RAND) {                  // viewport.rs:498-503
         o = cam_o;
-        d = (p00 + du * (float)px.i) + dv * (float)px.j;
+        d = (p00 + du * (float)px_i(px)) + dv * (float)px_j(px);
     } else {
         float jx, jy, rx, ry;
         if (samp<SPEC>(A) == RTW_SAMPLER_CENTRES) {              // Rust2/src/viewport.rs:92-104
-            const uint32_t kx = px.s / A.s_root, ly = px.s % A.s_root;
-            jx = ((float)px.i + ((float)kx + 0.5f) / (float)A.s_root) / (float)A.width;
-            jy = ((float)px.j + ((float)ly + 0.5f) / (float)A.s_root) / (float)A.height;
+            const uint32_t kx = px_s(px) / A.s_root, ly = px_s(px) % A.s_root;
+            jx = ((float)px_i(px) + ((float)kx + 0.5f) / (float)A.s_root) / (float)A.width;
+            jy = ((float)px_j(px) + ((float)ly + 0.5f) / (float)A.s_root) / (float)A.height;
             random_in_unit_disk(pt.rng, rx, ry, false, cn);
             o = cam_o + mk(rx, ry, 0.0f) * cam.lens_radius;
         } else {
             random_in_unit_disk(pt.rng, rx, ry, !SPEC && (A.flags & RTW_FLAG_CPP_DIFFUSE), cn);   // always drawn (viewport.rs:288)
             o = cam_o + (ld3(cam.u) * rx + ld3(cam.v) * ry) * cam.lens_radius;
             if (samp<SPEC>(A) == RTW_SAMPLER_ROW) {              // viewport.rs:290-297
-                jx = rng_offset(pt.rng, (float)px.i);
-                jy = rng_offset(pt.rng, (float)px.j);
+                jx = rng_offset(pt.rng, (float)px_i(px));
+                jy = rng_offset(pt.rng, (float)px_j(px));
                 tm = cam.time0 + cam.shutter * rng_f32(pt.rng);
             } else {                                         // viewport.rs:452-470 (x outer, y inner)
-                const uint32_t sx = px.s / A.s_root, sy = px.s % A.s_root;
-                jx = (float)px.i + (((float)sx + rng_f32(pt.rng)) / (float)A.s_root);
-                jy = (float)px.j + (((float)sy + rng_f32(pt.rng)) / (float)A.s_root);
+                const uint32_t sx = px_s(px) / A.s_root, sy = px_s(px) % A.s_root;
+                jx = (float)px_i(px) + (((float)sx + rng_f32(pt.rng)) / (float)A.s_root);
+                jy = (float)px_j(px) + (((float)sy + rng_f32(pt.rng)) / (float)A.s_root);
             }
         }
         d = (p00 + du * jx) + dv * jy;
@@ -314,35 +320,10 @@ __device__ __forceinline__ bool shade(const KArgs &A, Path &pt, int best, float 
 }
 
 // ---- specialised builds: a SHADE step in two halves around ONE rejection loop (sample_ball_or_disk, rtw_device.h) -------------------------
-// First half of shade<>() for the gradient integrator: miss -> sky; hit -> point, normal, material and Material::on_hit up to its random
-// unit vector.  Returns true when the path is finished.  Otherwise pt.o / pt.thr / pt.k are final; pt.d is final for a dielectric hit, and
-// for a diffuse / metallic one (need_ball) it holds the mirror direction until on_hit_second() has the unit vector (nrm, metal, front: what
-// that half needs of the hit).  A lane whose depth is exhausted needs no scatter direction at all: it is finished here.
-template <bool MOVING, int SPEC>
-__device__ __forceinline__ bool shade_first(const KArgs &A, Path &pt, int best, float best_t, bool &need_ball, v3 &nrm, float &metal, bool &front, Cen *cn = nullptr) {
-    RTW_CEN(cn, CEN_INFLIGHT);
-    const v3 ud = unit(pt.d);
-    if (best < 0) { RTW_CEN(cn, CEN_MISS); shade_miss<SPEC>(A, pt, ud); return true; }
-    RTW_CEN(cn, CEN_HIT);
-    const DevScene &sc = A.sc;
-    f4 g = sc.geom[best];
-    v3 c = mk(g.x, g.y, g.z);
-    if (MOVING) { f4 vv = sc.vel[best]; c = c + mk(vv.x, vv.y, vv.z) * pt.tm; }
-    const v3 point = pt.o + pt.d * best_t;                   // r.at(x)
-    const v3 normal = unit(point - c);                       // sphere.rs:127
-    const DevMat mat = sc.mat[best];
-    const v3 cm = (SPEC == 1 || SPEC == 3) ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
-    v3 next; bool fr;
-    const bool complete = on_hit_first(mat_params(mat), normal, pt.d, ud, pt.rng, next, fr, cn);
-    pt.thr = pt.thr * cm;
-    pt.o = point; pt.d = next;
-    pt.k++;
-    if (pt.k >= A.depth) { RTW_CEN(cn, CEN_DEPTH_END); pt.L = mk(0, 0, 0); return true; }      // depth exhausted: the innermost call returns black
-    need_ball = !complete; nrm = normal; metal = mat.metallicness; front = fr;
-    return false;
-}
-
-// ... the same from the hit on, for a lane whose unit(direction) `ud` the caller already has (and which is known not to end here).
+// The hit half of shade<>() for the gradient integrator, for a lane whose path goes on (the kernel has dealt with misses and exhausted depths):
+// point, normal, material and Material::on_hit up to its random unit vector.  pt.o / pt.thr are final afterwards; pt.d is final for a
+// dielectric hit, and for a diffuse / metallic one (need_ball) it holds the mirror direction until on_hit_second() has the unit vector
+// (nrm, metal, front: what that half needs of the hit).  `ud` = unit(pt.d), from the caller.  The bounce count lives in the kernel's flag word.
 template <bool MOVING, int SPEC>
 __device__ __forceinline__ void shade_hit_first(const KArgs &A, Path &pt, v3 ud, int best, float best_t, bool &need_ball, v3 &nrm, float &metal, bool &front, Cen *cn = nullptr) {
     RTW_CEN(cn, CEN_HIT);
@@ -358,22 +339,21 @@ __device__ __forceinline__ void shade_hit_first(const KArgs &A, Path &pt, v3 ud,
     const bool complete = on_hit_first(mat_params(mat), normal, pt.d, ud, pt.rng, next, fr, cn);
     pt.thr = pt.thr * cm;
     pt.o = point; pt.d = next;
-    pt.k++;
     need_ball = !complete; nrm = normal; metal = mat.metallicness; front = fr;
 }
 
 // start_path<>() for the render_row sampler (viewport.rs:286-297), in two halves around the lens-disk draw.
 __device__ __forceinline__ void start_path_first(const Pixel &px, Path &pt, Cen *cn = nullptr) {
     RTW_CEN(cn, CEN_START_PATH);
-    pt.rng = rng_start(px.rng_base, px.s);
-    pt.thr = mk(1.0f, 1.0f, 1.0f); pt.L = mk(0, 0, 0); pt.poison = false; pt.k = 0;
+    pt.rng = rng_start(px.rng_base, px_s(px));
+    pt.thr = mk(1.0f, 1.0f, 1.0f); pt.L = mk(0, 0, 0); pt.poison = false;
 }
 __device__ __forceinline__ void start_path_second(const Pixel &px, Path &pt, float rx, float ry) {
     const RtwCamera cam = load_camera();
     const v3 cam_o = ld3(cam.origin), p00 = ld3(cam.pixel00), du = ld3(cam.delta_u), dv = ld3(cam.delta_v);
     const v3 o = cam_o + (ld3(cam.u) * rx + ld3(cam.v) * ry) * cam.lens_radius;       // viewport.rs:288-289
-    const float jx = rng_offset(pt.rng, (float)px.i);                               // viewport.rs:290-297
-    const float jy = rng_offset(pt.rng, (float)px.j);
+    const float jx = rng_offset(pt.rng, (float)px_i(px));                           // viewport.rs:290-297
+    const float jy = rng_offset(pt.rng, (float)px_j(px));
     const float tm = cam.time0 + cam.shutter * rng_f32(pt.rng);
     const v3 d = (p00 + du * jx) + dv * jy;
     pt.o = o; pt.d = d; pt.tm = tm;
@@ -399,17 +379,16 @@ __device__ __forceinline__ bool finish_path(const KArgs &A, Pixel &px, Path &pt,
     if (pt.poison) { const float qn = __builtin_nanf(""); pt.L = mk(qn, qn, qn); }
     float3 *dst = reinterpret_cast<float3 *>(A.samples + 3 * (size_t)px.slot);
     if (SPEC == 3 || (SPEC == 0 && (A.flags & RTW_FLAG_CHUNK_SUMS))) {        // one slot per unit, the unit's samples added into it in sample order
-        if (px.s & (RTW_SUM_CHUNK - 1u)) {      // (chunk_len == RTW_SUM_CHUNK in this mode, units start on multiples of it)
+        if (px_s(px) & (RTW_SUM_CHUNK - 1u)) {      // (chunk_len == RTW_SUM_CHUNK in this mode, units start on multiples of it)
             const float3 acc = *dst;
             pt.L = mk(acc.x, acc.y, acc.z) + pt.L;
         }
         *dst = make_float3(pt.L.x, pt.L.y, pt.L.z);
-        px.s++;
-        return px.s >= px.s_end;
+        return px_advance(px);
     }
     *dst = make_float3(pt.L.x, pt.L.y, pt.L.z);   // one 12-byte store
-    px.slot += 64u; px.s++;
-    return px.s >= px.s_end;
+    px.slot += 64u;
+    return px_advance(px);
 }
 
 // The pixel stage of the driver (viewport.rs:299-301): color = sum of the samples IN ORDER, / samples,
@@ -525,7 +504,7 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
 template <bool MOVING, int SPEC, bool GEOM>
 __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_GEOM_BRUTE_WAVES : 1) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
-    Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
+    Pixel px; px.ij = px.rng_base = px.s = px.slot = 0;
     Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = rs.tries = 0; rs.sub = blockIdx.x & ((1u << A.sub_shift) - 1u);
 #ifdef RTW_ENDTIMES
     rs.t_dry = 0ull;
@@ -883,9 +862,10 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
     enum : uint32_t { F_HAVE = 1u,       // owns a work unit
                       F_INFLIGHT = 2u,   // a closest-hit query is in flight / complete and waiting to be shaded
                       F_NEWPATH = 4u,    // the next SHADE step starts the next sample of the unit
-                      F_DONE = 8u };     // a finished path waits for the next SHADE step to bank it
+                      F_DONE = 8u,       // a finished path waits for the next SHADE step to bank it
+                      F_K_SHIFT = 8u };  // specialised builds: the path's bounce count (Path.k) in bits 8..31
     uint32_t fl = 0u;
-    Pixel px; px.i = px.j = px.rng_base = px.s = px.s_end = px.slot = 0;
+    Pixel px; px.ij = px.rng_base = px.s = px.slot = 0;
     Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = rs.tries = 0; rs.sub = blockIdx.x & ((1u << A.sub_shift) - 1u);
 #ifdef RTW_ENDTIMES
     rs.t_dry = 0ull;
@@ -949,24 +929,6 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             if constexpr (SPEC != 0 && !GEOM) {
             // ---- specialised builds: the step in two halves around one rejection loop for the scatter directions AND the lens samples ----
             bool need_ball = false, need_disk = false, front = false;
-#ifndef RTW_SHADE_ORDER
-#define RTW_SHADE_ORDER 2
-#endif
-#if RTW_SHADE_ORDER == 1
-#ifdef RTW_SHADE_ZINIT
-            v3 nrm = mk(0, 0, 0); float metal = 0.0f;
-#else
-            v3 nrm; float metal;
-#endif
-            if (shading) {
-                RTW_CEN(cn, CEN_SHADING);
-                // a. the closest-hit query this lane was waiting on is complete: sky, or the hit up to its random unit vector
-                if (fl & F_INFLIGHT) {
-                    fl &= ~F_INFLIGHT;
-                    if (shade_first<MOVING, SPEC>(A, pt, tr.best, tr.best_t, need_ball, nrm, metal, front, cn)) fl |= F_DONE;
-                }
-            }
-#else
             // a. the closest-hit query this lane was waiting on is complete.  Paths that END here -- the ray missed (sky), or its depth is
             //    exhausted (black) -- are finished first, so that their lanes' next camera rays and the hits' scatter directions meet in ONE
             //    rejection loop further down; the lanes that hit keep unit(direction) until then.
@@ -979,11 +941,10 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
                     RTW_CEN(cn, CEN_INFLIGHT);
                     ud = unit(pt.d);
                     if (tr.best < 0) { RTW_CEN(cn, CEN_MISS); shade_miss<SPEC>(A, pt, ud); fl |= F_DONE; }
-                    else if (pt.k + 1u >= A.depth) { RTW_CEN(cn, CEN_DEPTH_END); pt.L = mk(0, 0, 0); fl |= F_DONE; }   // depth exhausted: the innermost call returns black
-                    else hit = true;
+                    else if ((fl >> F_K_SHIFT) + 1u >= A.depth) { RTW_CEN(cn, CEN_DEPTH_END); pt.L = mk(0, 0, 0); fl |= F_DONE; }   // depth exhausted: the innermost call returns black
+                    else { hit = true; fl += 1u << F_K_SHIFT; }         // (the bounce count of these builds: Path.k is not carried)
                 }
             }
-#endif
             RTW_SUB_STAMP(0);
             if (shading) {
                 if (fl & F_DONE) { fl &= ~F_DONE; if (finish_path<SPEC>(A, px, pt, cn)) fl &= ~F_HAVE; else fl |= F_NEWPATH; }
@@ -999,18 +960,12 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
                 if (got) fl |= F_HAVE | F_NEWPATH;
                 if (exhausted) tr.node = (int)Code<stack_t>::DEAD;
                 // c. next camera ray, up to its lens sample
-                if ((fl & F_HAVE) && (fl & F_NEWPATH)) { fl &= ~F_NEWPATH; start_path_first(px, pt, cn); need_disk = true; started = true; }
+                if ((fl & F_HAVE) && (fl & F_NEWPATH)) { fl &= F_HAVE | F_INFLIGHT | F_DONE; start_path_first(px, pt, cn); need_disk = true; started = true; }   // (clears F_NEWPATH and the bounce count)
             }
-#if RTW_SHADE_ORDER != 1
             //    ... the hit, up to its random unit vector
             if (hit) shade_hit_first<MOVING, SPEC>(A, pt, ud, tr.best, tr.best_t, need_ball, nrm, metal, front, cn);
-#endif
             // d. ONE rejection loop: points of the unit ball for the lanes that scatter, of the unit disk for the lanes that start a path
-#ifdef RTW_SHADE_ZINIT
-            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-#else
             float sx, sy, sz;
-#endif
             sample_ball_or_disk(pt.rng, need_ball || need_disk, need_ball, sx, sy, sz, cn);
             if (need_ball) pt.d = on_hit_second(metal, nrm, pt.d, front, mk(sx, sy, sz));
             if (need_disk) start_path_second(px, pt, sx, sy);

@@ -365,7 +365,7 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     if (p->width == 0 || p->height == 0 || p->samples == 0) return RTW_E_INVALID;
     if (p->integrator > RTW_INTEGRATOR_RUST2 || p->sampler > RTW_SAMPLER_NO_RAND || p->accel > RTW_ACCEL_BVH) return RTW_E_INVALID;
     if (p->part_count > 1 && (p->row_block == 0 || p->part_index >= p->part_count)) return RTW_E_INVALID;
-    if ((uint64_t)p->width * p->height >= (1ull << 32)) return RTW_E_INVALID;
+    if (p->width > 65535u || p->height > 65535u) return RTW_E_INVALID;      // a lane keeps (column, row) in one register (rtw_kernels.hip Pixel)
     c->pend.t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(c->device));
 
@@ -406,7 +406,7 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     a.row_block = p->row_block ? p->row_block : 1; a.part_index = p->part_index; a.part_count = p->part_count;
     a.tiles_x = (p->width + 7) / 8;
     a.n_samples = sampler_count(p->sampler, p->samples, &a.s_root);
-    if (a.n_samples == 0) return RTW_E_INVALID;
+    if (a.n_samples == 0 || a.n_samples >= (1u << 24)) return RTW_E_INVALID;   // (sample index and samples left in the unit share a register)
     a.sampler = p->sampler; a.integrator = p->integrator; a.depth = p->depth;
     a.has_textures = c->has_textures ? 1u : 0u;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
@@ -657,7 +657,7 @@ extern "C" {
 int rtw_ctx_set_option(rtw_ctx *c, uint32_t key, double v) {
     if (!c || !(v == v)) return RTW_E_INVALID;
     switch (key) {
-    case RTW_OPT_CHUNK_LEN:      if (!(v >= 0.0 && v <= 4096.0)) return RTW_E_INVALID; c->opt_chunk_len = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_CHUNK_LEN:      if (!(v >= 0.0 && v <= 255.0)) return RTW_E_INVALID; c->opt_chunk_len = (uint32_t)v; return RTW_OK;
     case RTW_OPT_SAMPLE_BANK_GB: if (!(v > 0.0 && v <= 1048576.0)) return RTW_E_INVALID; c->opt_bank_bytes = (uint64_t)(v * (double)(1ull << 30)); return RTW_OK;
     case RTW_OPT_LDS_GEOM:       if (!(v >= -1.0 && v <= 1.0)) return RTW_E_INVALID; c->opt_lds_geom = (int)v; return RTW_OK;
     case RTW_OPT_BLOCKS_PER_CU:  if (!(v >= 0.0 && v <= 8.0)) return RTW_E_INVALID; c->opt_blocks_per_cu = (uint32_t)v; return RTW_OK;
