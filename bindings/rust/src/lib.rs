@@ -38,7 +38,8 @@ pub struct RtwParams { pub width: u32, pub height: u32, pub samples: u32, pub de
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]
 pub struct RtwStats { pub camera_rays: u64, pub segments: u64, pub sphere_tests: u64, pub node_tests: u64,
     pub nan_pixels: u32, pub rows: u32, pub kernel_ms: f32, pub total_ms: f32,
-    pub phase_steps: [u64; 6], pub phase_lanes: [u64; 6], pub quad_tests: u64 }
+    pub phase_steps: [u64; 6], pub phase_lanes: [u64; 6], pub quad_tests: u64,
+    pub enqueue_ms: f32, pub start_ms: f32 }      // ABI v4: the call's timeline (rtw.h)
 
 #[repr(C)] pub struct RtwCtx { _private: [u8; 0] }
 #[repr(C)] pub struct RtwMgpu { _private: [u8; 0] }

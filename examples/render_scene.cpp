@@ -105,9 +105,11 @@ int main(int argc, char **argv) {
 
     std::vector<float> img((size_t)3 * p.width * p.height);
     RtwStats st;
+    std::vector<RtwStats> timeline;
     if (!devices.empty()) {                         // one frame over several GPUs, straight into this host buffer
         std::vector<RtwStats> per(devices.size());
         if ((rc = rtw_render_multi_gpu(devices.data(), (uint32_t)devices.size(), &cam, &scene, &p, img.data(), per.data()))) return die("rtw_render_multi_gpu", rc);
+        timeline = per;
         st = per[0];
         for (size_t k = 1; k < per.size(); k++) {
             st.camera_rays += per[k].camera_rays; st.segments += per[k].segments; st.nan_pixels += per[k].nan_pixels;
@@ -118,6 +120,12 @@ int main(int argc, char **argv) {
     std::printf("%u spheres + %u quads + %u instances, %ux%u, %llu camera rays, %llu segments, %.3f ms on the GPU (%.2f Gsegments/s), %u NaN pixels\n",
                 ns, scene.n_quads, scene.n_instances, p.width, p.height, (unsigned long long)st.camera_rays, (unsigned long long)st.segments, st.kernel_ms,
                 st.segments / (st.kernel_ms * 1e6), st.nan_pixels);
+    // the fork's timeline (rtw.h RtwStats, ABI v4): every device's launches are issued before any device's copy toward this (pageable) buffer,
+    // so `enqueue` stays far below `kernel` for every device (a one-shot call also pays its first-use allocations there); on distinct GPUs every
+    // `start` is near zero
+    for (size_t k = 0; k < timeline.size(); k++)
+        std::printf("device %d (part %zu of %zu): %u rows, enqueue returned after %.3f ms, kernels start %.3f ms after the call began, kernel %.3f ms, joined after %.3f ms\n",
+                    devices[k], k, timeline.size(), timeline[k].rows, timeline[k].enqueue_ms, timeline[k].start_ms, timeline[k].kernel_ms, timeline[k].total_ms);
     const bool ppm = out.size() > 4 && out.substr(out.size() - 4) == ".ppm";
     rc = ppm ? rtw_write_ppm_f32(out.c_str(), img.data(), p.width, p.height) : rtw_write_png_f32(out.c_str(), img.data(), p.width, p.height);
     if (rc) return die(out.c_str(), rc);

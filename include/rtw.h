@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTW_ABI_VERSION 3
+#define RTW_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
 #define RTW_OK              0
@@ -223,6 +223,12 @@ typedef struct RtwStats {
     uint64_t phase_steps[6];
     uint64_t phase_lanes[6];
     uint64_t quad_tests;     /* ray/quad plane tests (top-level quads and instance members) */
+    /* v4: the call's timeline.  enqueue_ms: host time from the begin of the call (rtw_mgpu_render: of the whole call, the same instant for
+     * every device) until this context's kernels had been issued; start_ms: device time from a marker recorded on this context's stream at
+     * the begin of the call (before any device was given work) to the start of its first kernel.  A fork that is asynchronous shows
+     * enqueue_ms far below kernel_ms for EVERY device, and on distinct GPUs start_ms near zero for every device. */
+    float    enqueue_ms;
+    float    start_ms;
 } RtwStats;
 
 typedef struct rtw_ctx rtw_ctx;
@@ -287,8 +293,13 @@ int  rtw_ctx_set_option(rtw_ctx *ctx, uint32_t key, double value);
  * (RtwParams.row_block, 8 when 0; device k renders the rows r with (r / row_block) % n_devices == k) and every device
  * copies its blocks STRAIGHT INTO their image rows of the caller's frame (one strided 2-D copy per device, no gather
  * buffer, no de-interleave pass).  The counter-based RNG makes the image independent of the split: the result is bit-identical
- * to rtw_ctx_render of the whole frame on one GPU.  One host thread drives all devices (launches are asynchronous); the call
- * blocks until the frame is complete.  `devices` are HIP ordinals and may repeat (several contexts on one GPU).
+ * to rtw_ctx_render of the whole frame on one GPU.  One host thread drives all devices; the call blocks until the frame is
+ * complete.  The fork is asynchronous by construction: first every device is prepared (arguments, first-use allocations), then
+ * every device's kernels are issued, and only then the copies toward the caller's frame -- none of which waits for a GPU: a frame
+ * in device memory or in pinned host memory (hipHostMalloc / hipHostRegister) receives the strided copies directly, a frame in
+ * ordinary pageable host memory (where a device-to-host copy would return only when it is done) is staged through a pinned buffer
+ * per device and finished by the host at the join.  RtwStats.enqueue_ms / start_ms of per_device[] show the timeline.
+ * `devices` are HIP ordinals and may repeat (several contexts on one GPU).  NOT YET MEASURED on more than one physical GPU.
  * out_rgb: the full [height][width][3] f32 frame, host memory or device memory of any of the GPUs.
  * params->part_count must be <= 1.  per_device (may be NULL): n_devices RtwStats; total (may be NULL): counters summed,
  * kernel_ms = the slowest device, total_ms = host wall time of the call. */

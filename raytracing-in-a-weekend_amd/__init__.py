@@ -106,7 +106,8 @@ class RtwStats(C.Structure):
     _fields_ = [("camera_rays", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("node_tests", C.c_uint64), ("nan_pixels", C.c_uint32), ("rows", C.c_uint32),
                 ("kernel_ms", C.c_float), ("total_ms", C.c_float),
-                ("phase_steps", C.c_uint64 * 6), ("phase_lanes", C.c_uint64 * 6), ("quad_tests", C.c_uint64)]
+                ("phase_steps", C.c_uint64 * 6), ("phase_lanes", C.c_uint64 * 6), ("quad_tests", C.c_uint64),
+                ("enqueue_ms", C.c_float), ("start_ms", C.c_float)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k.startswith("phase_") else getattr(self, k)) for k, _ in self._fields_}

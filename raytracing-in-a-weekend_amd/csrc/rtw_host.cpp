@@ -11,7 +11,7 @@
 
 // The ABI's PODs have no implicit padding (the ctypes / Rust mirrors rely on these sizes).
 static_assert(sizeof(RtwCamera) == 84 && sizeof(RtwSphere) == 80 && sizeof(RtwTexture) == 16 && sizeof(RtwQuad) == 88, "POD layout");
-static_assert(sizeof(RtwInstance) == 48 && sizeof(RtwScene) == 96 && sizeof(RtwParams) == 72 && sizeof(RtwStats) == 152, "POD layout");
+static_assert(sizeof(RtwInstance) == 48 && sizeof(RtwScene) == 96 && sizeof(RtwParams) == 72 && sizeof(RtwStats) == 160, "POD layout");
 
 namespace rtw {
 

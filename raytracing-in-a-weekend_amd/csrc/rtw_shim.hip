@@ -30,6 +30,7 @@ struct rtw_ctx {
     int n_cu = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_mark = nullptr;        // "the call began", recorded on this context's stream before anything of the call is launched anywhere (RtwStats.start_ms)
     // scene
     bool has_scene = false;
     bool has_textures = false;
@@ -48,6 +49,8 @@ struct rtw_ctx {
     unsigned long long *h_stats = nullptr;   // pinned: the counter read-back is a true async copy
     float *d_out = nullptr;
     size_t d_out_cap = 0;
+    float *h_out = nullptr;              // pinned staging for a multi-GPU frame in PAGEABLE host memory: a device-to-host copy into pageable memory returns only
+    size_t h_out_cap = 0;                // when it is done, which would hold the fork of rtw_mgpu_render at this device until it has rendered its share
     uint32_t *d_order = nullptr;         // RTW_OPT_TILE_ORDER: queue position -> tile, valid for order_key
     size_t d_order_cap = 0;
     TileOrderKey order_key{};
@@ -73,8 +76,14 @@ struct rtw_ctx {
     // the render in flight between render_enqueue and render_wait
     struct Pending {
         bool active = false;
+        bool marked = false;             // ev_mark was recorded for this call (by rtw_mgpu_render, before any device was given work)
         uint32_t n_rows = 0;
-        std::chrono::steady_clock::time_point t0;
+        std::chrono::steady_clock::time_point t0;      // the call's begin on the host (rtw_mgpu_render: the same instant for every device)
+        float enqueue_ms = 0.0f;         // host time from t0 until this context's launches had been issued
+        // where the rendered rows go (render_copy / render_wait)
+        float *dst = nullptr; bool scatter = false, direct = false, staged = false;
+        uint32_t width = 0, height = 0, row_block = 1, part_index = 0, part_count = 1;
+        size_t out_bytes = 0;
     } pend;
 };
 
@@ -177,6 +186,7 @@ int rtw_ctx_create(int device, rtw_ctx **out) {
     if (e == hipSuccess) { c->n_cu = prop.multiProcessorCount; e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking); }
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_mark);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, RTW_QUEUE_BYTES);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_stats, RTW_N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stats, RTW_N_STATS * sizeof(unsigned long long), hipHostMallocDefault);
@@ -201,6 +211,8 @@ void rtw_ctx_destroy(rtw_ctx *c) {
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->ev_mark) (void)hipEventDestroy(c->ev_mark);
     if (c->d_samples) (void)hipFree(c->d_samples);
     if (c->d_order) (void)hipFree(c->d_order);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -344,12 +356,29 @@ static int scatter_rows(rtw_ctx *c, const float *src, float *dst, uint32_t width
     return RTW_OK;
 }
 
-static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out);
+// ... the same on the host, from the pinned staging buffer into a pageable frame (render_wait)
+static void scatter_rows_host(const float *src, float *dst, uint32_t width, uint32_t height, uint32_t n_rows, uint32_t row_block, uint32_t part_index, uint32_t part_count) {
+    const size_t row_floats = (size_t)width * 3;
+    if (part_count <= 1) { std::memcpy(dst, src, row_floats * height * sizeof(float)); return; }
+    for (uint32_t k = 0; k < n_rows; k += row_block) {               // compact rows [k, k + rows) are image rows [j, j + rows)
+        const uint32_t j = ((k / row_block) * part_count + part_index) * row_block;
+        const uint32_t rows = std::min(row_block, std::min(n_rows - k, height - j));
+        std::memcpy(dst + (size_t)j * row_floats, src + (size_t)k * row_floats, rows * row_floats * sizeof(float));
+    }
+}
+
+// A render is three phases: PREPARE (argument checks, first-use allocations, driver queries: may wait for the device), LAUNCH (memsets, kernels,
+// events, counter read-back: never waits), COPY (the rows toward the caller's memory: never waits for the device either -- a pageable multi-GPU
+// host frame is staged through pinned memory and finished on the host in render_wait).  rtw_ctx_render runs them back to back; rtw_mgpu_render
+// runs each phase for EVERY device before the next phase for any, so that no device's work is held up by another's.
+enum : unsigned { PH_PREPARE = 1u, PH_LAUNCH = 2u, PH_COPY = 4u, PH_ALL = 7u };
+static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out, unsigned phases);
+static int render_copy(rtw_ctx *c);
 
 // Launch one render on the context's stream; nothing here waits for the GPU (apart from a first-use hipMalloc).  On failure nothing of
 // this call is left running: whatever was already launched is waited for, so the caller may free or reuse its buffers at once.
-static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out) {
-    const int rc = render_enqueue_impl(c, cam, p, out);
+static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out, unsigned phases = PH_ALL) {
+    const int rc = render_enqueue_impl(c, cam, p, out, phases);
     if (rc != RTW_OK && c && c->stream && !c->pend.active) {
         const int keep = g_last_hip;
         if (hipStreamSynchronize(c->stream) != hipSuccess) (void)hipGetLastError();
@@ -358,7 +387,7 @@ static int render_enqueue(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, 
     return rc;
 }
 
-static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out) {
+static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams *p, OutSpec out, unsigned phases) {
     if (!c || !cam || !p || !out.base) return RTW_E_INVALID;
     if (c->pend.active) return RTW_E_INVALID;
     if (!c->has_scene) return RTW_E_NO_SCENE;
@@ -366,7 +395,7 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     if (p->integrator > RTW_INTEGRATOR_RUST2 || p->sampler > RTW_SAMPLER_NO_RAND || p->accel > RTW_ACCEL_BVH) return RTW_E_INVALID;
     if (p->part_count > 1 && (p->row_block == 0 || p->part_index >= p->part_count)) return RTW_E_INVALID;
     if (p->width > 65535u || p->height > 65535u) return RTW_E_INVALID;      // a lane keeps (column, row) in one register (rtw_kernels.hip Pixel)
-    c->pend.t0 = std::chrono::steady_clock::now();
+    if (!c->pend.marked) c->pend.t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(c->device));
 
     // The BVH's pruning is proven against the reference's ROUNDED quadratic (DESIGN.md "Conservative traversal"), which presumes
@@ -460,15 +489,25 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     // destination: the kernels write compact rows either straight into the caller's device buffer or into the context's
     const size_t out_bytes = (size_t)n_rows * p->width * 3 * sizeof(float);
     // (asked on every call, a few microseconds: the same address can be host memory in one call and device memory in the next)
+    bool pinned_host = false;
     {
         hipPointerAttribute_t attr;
         c->attr_on_device = false; c->attr_device = -1;
         if (hipPointerGetAttributes(&attr, out.base) == hipSuccess) {
             c->attr_on_device = attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+            pinned_host = attr.type == hipMemoryTypeHost;          // hipHostMalloc / hipHostRegister: a copy into it is a true asynchronous DMA
             c->attr_device = attr.device;
         } else (void)hipGetLastError();
     }
     const bool direct = c->attr_on_device && c->attr_device == c->device && !(out.scatter && p->part_count > 1);
+    // A multi-GPU frame in pageable host memory (the reference's Img, a Vec, a numpy array): staged through this context's pinned buffer
+    const bool staged = out.scatter && !c->attr_on_device && !pinned_host;
+    if (staged && c->h_out_cap < out_bytes) {
+        if (c->h_out) (void)hipHostFree(c->h_out);
+        c->h_out = nullptr; c->h_out_cap = 0;
+        if (hipHostMalloc((void **)&c->h_out, out_bytes ? out_bytes : 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return RTW_E_NOMEM; }
+        c->h_out_cap = out_bytes;
+    }
     if (direct) a.out = out.base;
     else {
         if (c->d_out_cap < out_bytes) {
@@ -513,6 +552,9 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         per_cu = it->second;
     }
 
+    if (!(phases & PH_LAUNCH)) return RTW_OK;          // PREPARE only: everything that can wait for the device is behind us
+
+    if (!c->pend.marked) HIP_TRY(hipEventRecord(c->ev_mark, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, RTW_N_STATS * sizeof(unsigned long long), c->stream));
 #ifdef RTW_ENDTIMES
     HIP_TRY(hipMemsetAsync(c->d_stats + 24, 0xFF, sizeof(unsigned long long), c->stream));     // atomicMin targets (diagnostic build only)
@@ -585,21 +627,41 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, RTW_N_STATS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    if (out.scatter) {
-        if (!direct) { int rc = scatter_rows(c, c->d_out, out.base, p->width, p->height, a.row_block, p->part_index, p->part_count); if (rc != RTW_OK) return rc; }
-    } else if (!direct) HIP_TRY(hipMemcpyAsync(out.base, c->d_out, out_bytes, hipMemcpyDefault, c->stream));
     c->pend.active = true; c->pend.n_rows = n_rows;
+    c->pend.dst = out.base; c->pend.scatter = out.scatter; c->pend.direct = direct; c->pend.staged = staged;
+    c->pend.width = p->width; c->pend.height = p->height; c->pend.row_block = a.row_block; c->pend.part_index = p->part_index; c->pend.part_count = p->part_count;
+    c->pend.out_bytes = out_bytes;
+    c->pend.enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->pend.t0).count();
+    if (phases & PH_COPY) return render_copy(c);
+    return RTW_OK;
+}
+
+// COPY phase: the rendered rows toward the caller's memory, queued behind the kernels on the context's stream.
+static int render_copy(rtw_ctx *c) {
+    if (!c || !c->pend.active) return RTW_E_INVALID;
+    const rtw_ctx::Pending &q = c->pend;
+    if (q.direct) return RTW_OK;                        // the kernels wrote into the caller's device buffer
+    HIP_TRY(hipSetDevice(c->device));
+    if (q.staged) {                                     // pinned staging now (a true asynchronous copy), the caller's pageable frame in render_wait
+        HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, q.out_bytes, hipMemcpyDeviceToHost, c->stream));
+    } else if (q.scatter) {
+        const int rc = scatter_rows(c, c->d_out, q.dst, q.width, q.height, q.row_block, q.part_index, q.part_count);
+        if (rc != RTW_OK) return rc;
+    } else HIP_TRY(hipMemcpyAsync(q.dst, c->d_out, q.out_bytes, hipMemcpyDefault, c->stream));
     return RTW_OK;
 }
 
 // Wait for the render launched by render_enqueue and report its counters.
 static int render_wait(rtw_ctx *c, RtwStats *stats) {
     if (!c || !c->pend.active) return RTW_E_INVALID;
-    c->pend.active = false;
+    c->pend.active = false; c->pend.marked = false;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    float ms = 0.0f;
+    if (c->pend.staged)
+        scatter_rows_host(c->h_out, c->pend.dst, c->pend.width, c->pend.height, c->pend.n_rows, c->pend.row_block, c->pend.part_index, c->pend.part_count);
+    float ms = 0.0f, start_ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    HIP_TRY(hipEventElapsedTime(&start_ms, c->ev_mark, c->ev0));
     const unsigned long long *h_stats = c->h_stats;
     const bool kernel_gave_up = h_stats[23] != 0ull;           // safety valve of the persistent loop (rtw_kernels.hip RTW_MAX_TRIPS)
     if (stats) {
@@ -609,6 +671,7 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
         stats->nan_pixels = (uint32_t)h_stats[4]; stats->rows = c->pend.n_rows;
         stats->quad_tests = h_stats[14];
         stats->kernel_ms = ms;
+        stats->enqueue_ms = c->pend.enqueue_ms; stats->start_ms = start_ms;
         for (int k = 0; k < 3; k++) { stats->phase_steps[k] = h_stats[5 + k]; stats->phase_lanes[k] = h_stats[8 + k]; }
         for (int k = 3; k < 5; k++) { stats->phase_steps[k] = h_stats[16 + 2 * (k - 3)]; stats->phase_lanes[k] = h_stats[17 + 2 * (k - 3)]; }
 #ifdef RTW_CENSUS                                   // diagnostic build only (scripts/gpu_census.py): lanes live in the sub-blocks of a SHADE step
@@ -725,16 +788,30 @@ int rtw_mgpu_render(rtw_mgpu *m, const RtwCamera *cam, const RtwParams *params, 
     if (!m || !cam || !params || !out_rgb || params->part_count > 1) return RTW_E_INVALID;
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t n = (uint32_t)m->ctx.size();
-    // fork: viewport.rs:236-240 spawns one task per row; here one asynchronous launch sequence per device
+    // fork: viewport.rs:236-240 spawns one task per row; here one asynchronous launch sequence per device, in three passes so that nothing
+    // one device needs -- a first-use allocation, a driver query, a copy toward the caller's frame -- can delay the start of another:
+    //   0. every device: mark the begin of the call on its stream, check the arguments, allocate what this frame shape needs (may wait)
+    //   1. every device: memsets, kernels, events, counter read-back (never waits)
+    //   2. every device: its rows toward the frame -- strided copies into device or pinned memory, pinned staging for a pageable frame
     int rc = RTW_OK;
+    auto part = [&](uint32_t k) { RtwParams q = *params; q.row_block = params->row_block ? params->row_block : 8u; q.part_index = k; q.part_count = n; return q; };
+    for (uint32_t k = 0; k < n && rc == RTW_OK; k++) {
+        rtw_ctx *c = m->ctx[k];
+        if (c->pend.active) { rc = RTW_E_INVALID; break; }
+        c->pend.t0 = t0;
+        if (hipSetDevice(c->device) != hipSuccess || hipEventRecord(c->ev_mark, c->stream) != hipSuccess) { (void)hipGetLastError(); rc = RTW_E_HIP; break; }
+        c->pend.marked = true;
+        const RtwParams q = part(k);
+        rc = render_enqueue(c, cam, &q, OutSpec{ out_rgb, true }, PH_PREPARE);
+    }
     uint32_t launched = 0;
-    for (; launched < n; launched++) {
-        RtwParams q = *params;
-        q.row_block = params->row_block ? params->row_block : 8u;
-        q.part_index = launched; q.part_count = n;
-        rc = render_enqueue(m->ctx[launched], cam, &q, OutSpec{ out_rgb, true });
+    for (; launched < n && rc == RTW_OK; launched++) {
+        const RtwParams q = part(launched);
+        rc = render_enqueue(m->ctx[launched], cam, &q, OutSpec{ out_rgb, true }, PH_PREPARE | PH_LAUNCH);
         if (rc != RTW_OK) break;
     }
+    for (uint32_t k = 0; k < launched && rc == RTW_OK; k++) rc = render_copy(m->ctx[k]);
+    for (uint32_t k = 0; k < n; k++) m->ctx[k]->pend.marked = m->ctx[k]->pend.active && m->ctx[k]->pend.marked;
     // join: viewport.rs:241-244 awaits the tasks in order
     RtwStats sum; std::memset(&sum, 0, sizeof sum);
     for (uint32_t k = 0; k < launched; k++) {
@@ -746,6 +823,8 @@ int rtw_mgpu_render(rtw_mgpu *m, const RtwCamera *cam, const RtwParams *params, 
         sum.node_tests += st.node_tests; sum.quad_tests += st.quad_tests; sum.nan_pixels += st.nan_pixels; sum.rows += st.rows;
         for (int i = 0; i < 6; i++) { sum.phase_steps[i] += st.phase_steps[i]; sum.phase_lanes[i] += st.phase_lanes[i]; }
         if (st.kernel_ms > sum.kernel_ms) sum.kernel_ms = st.kernel_ms;
+        if (st.enqueue_ms > sum.enqueue_ms) sum.enqueue_ms = st.enqueue_ms;          // (the last device's: the fork's length on the host)
+        if (st.start_ms > sum.start_ms) sum.start_ms = st.start_ms;                // (the latest kernel start)
     }
     sum.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (total) *total = sum;

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 17, names
     for n in names:
         assert hasattr(L, n), f"librtw_hip.so does not export {n}"
-    assert L.rtw_abi_version() == 3
+    assert L.rtw_abi_version() == 4
 
 
 def test_oracle_exports_every_declared_symbol():
@@ -40,7 +40,7 @@ def test_pod_sizes_match_header():
     assert C.sizeof(R.RtwSphere) == 80
     assert C.sizeof(R.RtwTexture) == 16
     assert C.sizeof(R.RtwParams) == 72
-    assert C.sizeof(R.RtwStats) == 152
+    assert C.sizeof(R.RtwStats) == 160
     assert C.sizeof(R.RtwScene) == 96
     assert C.sizeof(R.RtwQuad) == 88
     assert C.sizeof(R.RtwInstance) == 48
