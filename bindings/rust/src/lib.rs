@@ -12,7 +12,7 @@ pub struct RtwSphere { pub center: [f32; 3], pub radius: f32, pub velocity: [f32
     pub tex_color: [f32; 3], pub metallicness: f32, pub opacity: f32, pub ir: f32, pub emitted: [f32; 3], pub tex: i32 }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
-pub struct RtwTexture { pub row: u32, pub col: u32, pub texel_offset: u32, pub reserved: u32 }
+pub struct RtwTexture { pub row: u32, pub col: u32, pub texel_offset: u32, pub emit_tex: u32 }   // emit_tex: 1 + index of Rust2's emission image, 0 = none
 
 /// `Quad` (objects/quad.rs:8-20) + its Material; normal / d / w of Quad::new are recomputed by the library.
 #[repr(C)] #[derive(Clone, Copy, Default)]

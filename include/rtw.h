@@ -111,7 +111,8 @@ typedef struct RtwTexture {
     uint32_t row;
     uint32_t col;
     uint32_t texel_offset;
-    uint32_t reserved;
+    uint32_t emit_tex;    /* RTW_INTEGRATOR_RUST2 only: 1 + index of the texture that holds Rust2's `emmit_img` for this image
+                             (Rust2/src/objects/texture.rs:34-41), 0 = none (the sphere's `emitted` is used).  Was `reserved` (0) up to v3. */
 } RtwTexture;
 
 /* `Quad` (Rust/src/objects/quad.rs:8-20) with its `Material` inlined.  The derived fields of Quad::new

@@ -58,6 +58,10 @@ float rtw_oracle_rng_next(uint32_t state[2]);
 float rtw_oracle_ln(float x);
 void  rtw_oracle_ln_bulk(const float *x, float *out, size_t n);
 
+/* Rust2's ImageTexture::color_at index rule (Rust2/src/objects/texture.rs:94-105): x * width + y with x = (u * width) as usize, y = (v * height)
+ * as usize (emission != 0: floor() first, as :95-96 write it), clamped to the last texel where the reference would panic. */
+uint32_t rtw_oracle_rust2_texel_index(float u, float v, uint32_t width, uint32_t height, int emission);
+
 /* Vec3::rotated (Rust/src/vec3.rs:161-181), for the reference's rotation_tests known answers (vec3.rs:363-404). */
 void  rtw_oracle_rotated(const float v[3], const float rot[3], float out[3]);
 

@@ -189,6 +189,35 @@ static v3 sphere_albedo(const RtwScene *sc, const RtwSphere *s, v3 normal) {
     return v3_mul(tex, v3_ld(s->col_mod));        /* sphere.rs:145 */
 }
 
+/* Rust2's ImageTexture::color_at (Rust2/src/objects/texture.rs:94-105) as written: the sample of an image of `width` x `height` texels at
+ * (u, v) is img[x * width + y] with x = (u * width) as usize, y = (v * height) as usize -- scaled by the size (not size - 1 as in Rust/) and
+ * indexed TRANSPOSED (x * width + y, not y * width + x: most likely a bug, and part of the contract); the emission image
+ * uses floor() before the cast (:95-96), which is the same index for the non-negative u, v a sphere produces.  The reference panics when the
+ * index leaves the Vec (u == 1, or a tall image); the restatement and the device clamp it to the last texel. */
+static inline size_t rust2_texel_index(float u, float v, uint32_t width, uint32_t height, int floor_first) {
+    const float fx = u * (float)width, fy = v * (float)height;
+    const uint64_t x = f32_as_usize(floor_first ? floorf(fx) : fx), y = f32_as_usize(floor_first ? floorf(fy) : fy);
+    const uint64_t idx = x * (uint64_t)width + y, last = (uint64_t)width * height - 1u;
+    return (size_t)(idx > last ? last : idx);
+}
+uint32_t rtw_oracle_rust2_texel_index(float u, float v, uint32_t width, uint32_t height, int emission) {
+    return (uint32_t)rust2_texel_index(u, v, width, height, emission);
+}
+/* Rust2 Sphere::color (Rust2/src/objects/sphere.rs:92-107) for a sphere with an image texture: ColorResult{emmited, multiplied}.  `multiplied`
+ * is the texel (times the POD's col_mod, which a Rust2 scene leaves at 1: x * 1.0 == x); `emmited` the texel of the texture's emission
+ * image (RtwTexture.emit_tex), or the sphere's constant emission when it has none. */
+static void rust2_sphere_color(const RtwScene *sc, const RtwSphere *s, v3 normal, v3 *mult, v3 *emit) {
+    const RtwTexture *t = &sc->textures[s->tex];
+    const float PI = 3.14159265358979323846f, FRAC_1_PI = 0.318309886183790671538f;
+    const float u = (atan2f(-normal.z, normal.x) + PI) * FRAC_1_PI * 0.5f;
+    const float v = 1.0f - (FRAC_1_PI * acosf(-normal.y));
+    *mult = v3_mul(v3_ld(&sc->texels[3 * ((size_t)t->texel_offset + rust2_texel_index(u, v, t->row, t->col, 0))]), v3_ld(s->col_mod));
+    if (t->emit_tex != 0 && t->emit_tex <= sc->n_textures) {
+        const RtwTexture *e = &sc->textures[t->emit_tex - 1];
+        *emit = v3_ld(&sc->texels[3 * ((size_t)e->texel_offset + rust2_texel_index(u, v, e->row, e->col, 1))]);
+    } else *emit = v3_ld(s->emitted);
+}
+
 /* sphere.rs:99-147.  Returns 1 and fills *t (no normal yet) when the sphere reports Some(Hit). */
 static inline int sphere_hit_t(const RtwSphere *s, ray_t r, float mint, float maxt, float *t_out, v3 *centre_out) {
     v3 origin = v3_add(v3_ld(s->center), v3_scale(v3_ld(s->velocity), r.time)); /* :100 */
@@ -643,6 +672,15 @@ static ray_t rust2_on_hit(const mat_t *s, const hit_t *h, ray_t r, rng_t *rng, u
     return o;
 }
 
+/* A top-level sphere with an image texture takes its ColorResult from Rust2's own lookup rule (instance members keep the Rust/ rule: instances
+ * are the Rust/ tree's, Rust2 has none). */
+static void rust2_color_override(const RtwScene *sc, const hit_t *h, v3 *multiplied, v3 *emmited) {
+    if (h->sphere >= 0 && (uint32_t)h->sphere < sc->n_spheres) {
+        const RtwSphere *s = &sc->spheres[h->sphere];
+        if (s->tex >= 0 && (uint32_t)s->tex < sc->n_textures) rust2_sphere_color(sc, s, h->normal, multiplied, emmited);
+    }
+}
+
 /* Rust2 ray_color, the reference's recursion (Rust2/src/viewport/ray_color.rs:12-37). */
 static v3 ray_color_rust2_rec(ctx_t *c, ray_t r, uint32_t depth) {
     if (depth == 0) return v3_ld(c->sc->background);
@@ -651,8 +689,10 @@ static v3 ray_color_rust2_rec(ctx_t *c, ray_t r, uint32_t depth) {
         const mat_t *sp = &h.mat;
         ray_t next = rust2_on_hit(sp, &h, r, c->rng, c->p->flags);   /* o.color(&h) draws nothing; o.reflect(&h) does */
         trace_record(c, 1, &h, NULL, r);
+        v3 emmited = v3_ld(sp->emitted), multiplied = h.col_mod;
+        rust2_color_override(c->sc, &h, &multiplied, &emmited);
         v3 next_color = ray_color_rust2_rec(c, next, depth - 1);
-        return v3_add(v3_ld(sp->emitted), v3_mul(next_color, h.col_mod));   /* emmited + next.field_wise_mult(multiplied) */
+        return v3_add(emmited, v3_mul(next_color, multiplied));      /* emmited + next.field_wise_mult(multiplied) */
     }
     trace_record(c, 0, NULL, NULL, r);
     return v3_ld(c->sc->background);
@@ -670,8 +710,10 @@ static v3 ray_color_rust2_iter(ctx_t *c, ray_t r, uint32_t depth) {
         const mat_t *sp = &h.mat;
         ray_t next = rust2_on_hit(sp, &h, r, c->rng, c->p->flags);
         trace_record(c, 1, &h, NULL, r);
-        L = v3_add(L, v3_mul(v3_ld(sp->emitted), thr));
-        thr = v3_mul(thr, h.col_mod);
+        v3 emmited = v3_ld(sp->emitted), multiplied = h.col_mod;
+        rust2_color_override(c->sc, &h, &multiplied, &emmited);
+        L = v3_add(L, v3_mul(emmited, thr));
+        thr = v3_mul(thr, multiplied);
         r = next;
     }
     return v3_add(L, v3_mul(v3_ld(c->sc->background), thr));        /* depth == 0 returns the background */

@@ -71,7 +71,7 @@ class RtwSphere(C.Structure):
 
 
 class RtwTexture(C.Structure):
-    _fields_ = [("row", C.c_uint32), ("col", C.c_uint32), ("texel_offset", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("row", C.c_uint32), ("col", C.c_uint32), ("texel_offset", C.c_uint32), ("emit_tex", C.c_uint32)]
 
 
 class RtwQuad(C.Structure):
@@ -302,7 +302,9 @@ class Scene:
     """`Scene` (Rust/src/viewport.rs:79-151): spheres (+ image textures), quads, instances, background colour."""
 
     def __init__(self, spheres: Sequence, textures: Sequence[np.ndarray] = (), background=(0.0, 0.0, 0.0),
-                 quads: Sequence = (), instances: Sequence = ()):
+                 quads: Sequence = (), instances: Sequence = (), emission_images=None):
+        """`emission_images` {texture index: index of the texture that is its Rust2 `emmit_img`} (Rust2/src/objects/texture.rs:34-41;
+        RTW_INTEGRATOR_RUST2 only)."""
         pods = [s.pod if isinstance(s, Sphere) else s for s in spheres]
         self._spheres = (RtwSphere * max(1, len(pods)))(*pods)
         self.n_spheres = len(pods)
@@ -313,6 +315,8 @@ class Scene:
             descs.append(RtwTexture(w, h, off, 0))
             flat.append(img.reshape(-1, 3))
             off += w * h
+        for t, e in (emission_images or {}).items():
+            descs[t].emit_tex = int(e) + 1
         self._textures = (RtwTexture * max(1, len(descs)))(*descs)
         self.n_textures = len(descs)
         self._texels = np.concatenate(flat, axis=0).astype(np.float32) if flat else np.zeros((1, 3), np.float32)

@@ -330,6 +330,28 @@ __device__ __forceinline__ v3 sphere_albedo(const DevScene &sc, const DevMat &m,
     return (ld3(px) * 1.0f) * ld3(m.cm);
 }
 
+// Rust2's ImageTexture::color_at (Rust2/src/objects/texture.rs:94-105), reached from Rust2's Sphere::color (Rust2/src/objects/sphere.rs:92-107):
+// multiplied = img[x * width + y] with x = (u * width) as usize, y = (v * height) as usize -- scaled by the size, not size - 1, and indexed
+// TRANSPOSED (part of the contract: SURVEY.md 8 a10) --; emmited = emmit_img[emmit_x * emmit_width + emmit_y] with floor() before the casts.
+// Where the reference would panic (an index past the Vec: u == 1, tall images) the index is clamped to the last texel, as in the oracle.
+__device__ __forceinline__ uint32_t rust2_texel_index(float u, float v, uint32_t width, uint32_t height, bool floor_first) {
+    const float fx = u * (float)width, fy = v * (float)height;
+    const uint64_t x = tex_index(floor_first ? floorf(fx) : fx, 0xFFFFFFFFu), y = tex_index(floor_first ? floorf(fy) : fy, 0xFFFFFFFFu);
+    const uint64_t idx = x * (uint64_t)width + y, last = (uint64_t)width * height - 1u;
+    return (uint32_t)(idx > last ? last : idx);
+}
+__device__ __forceinline__ void rust2_sphere_color(const DevScene &sc, const DevMat &m, v3 normal, v3 &multiplied, v3 &emmited) {
+    const RtwTexture t = sc.tex[m.tex];
+    const float PI = 3.14159265358979323846f, FRAC_1_PI = 0.318309886183790671538f;
+    const float u = (atan2f(-normal.z, normal.x) + PI) * FRAC_1_PI * 0.5f;
+    const float v = 1.0f - (FRAC_1_PI * acosf(-normal.y));
+    multiplied = ld3(sc.texels + 3 * (size_t)(t.texel_offset + rust2_texel_index(u, v, t.row, t.col, false))) * ld3(m.cm);   // (cm = col_mod: 1 in a Rust2 scene)
+    if (t.emit_tex != 0u) {
+        const RtwTexture e = sc.tex[t.emit_tex - 1u];
+        emmited = ld3(sc.texels + 3 * (size_t)(e.texel_offset + rust2_texel_index(u, v, e.row, e.col, true)));
+    }
+}
+
 // materials.rs:89-97
 __device__ __forceinline__ v3 refract(v3 uv, v3 n, float etai_over_etat) {
     float cos_theta = dot(-uv, n);

@@ -316,7 +316,7 @@ int rtw_scene_generate(uint32_t which, uint64_t scene_seed,
         break;
     case RTW_SCENE_C5_MOTION_CHECKER: {
         // ground: 4x2 two-colour image through the sphere-UV lookup (squares.png-like, texture.rs:259-267)
-        RtwTexture t; t.row = 4; t.col = 2; t.texel_offset = 0; t.reserved = 0; tx.push_back(t);
+        RtwTexture t; t.row = 4; t.col = 2; t.texel_offset = 0; t.emit_tex = 0; tx.push_back(t);
         for (int y = 0; y < 2; y++) for (int x = 0; x < 4; x++) {
             bool dark = ((x + y) & 1) != 0;
             const float c[3] = { dark ? 0.2f : 0.9f, dark ? 0.3f : 0.9f, dark ? 0.1f : 0.9f };

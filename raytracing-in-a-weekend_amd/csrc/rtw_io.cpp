@@ -203,7 +203,7 @@ int rtw_scene_from_json(const char *text, size_t len,
             if (img->arr.size() < (size_t)w * h) return RTW_E_INVALID;
             if (w == 1 && h == 1) { if (!read_vec3(&img->arr[0], s.tex_color)) return RTW_E_INVALID; }
             else {
-                RtwTexture d; d.row = w; d.col = h; d.texel_offset = (uint32_t)(tl.size() / 3); d.reserved = 0;
+                RtwTexture d; d.row = w; d.col = h; d.texel_offset = (uint32_t)(tl.size() / 3); d.emit_tex = 0;
                 for (size_t k = 0; k < (size_t)w * h; k++) { float c[3]; if (!read_vec3(&img->arr[k], c)) return RTW_E_INVALID; tl.insert(tl.end(), c, c + 3); }
                 s.tex = (int32_t)tx.size(); tx.push_back(d);
             }

@@ -305,8 +305,10 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, v3 ud, int b
     const v3 point = pt.o + pt.d * best_t;                   // r.at(x)
     const v3 normal = unit(point - c);                       // sphere.rs:127
     const DevMat mat = sc.mat[best];
-    const v3 cm = (SPEC == 1 || SPEC == 3) ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
-    return shade_surface<SPEC>(A, pt, ud, point, normal, cm, mat_params(mat), ld3(mat.emitted), cn);
+    v3 cm, emitted = ld3(mat.emitted);
+    if (!SPEC && A.integrator == RTW_INTEGRATOR_RUST2 && mat.tex >= 0) rust2_sphere_color(sc, mat, normal, cm, emitted);     // Rust2's own lookup rule
+    else cm = (SPEC == 1 || SPEC == 3) ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
+    return shade_surface<SPEC>(A, pt, ud, point, normal, cm, mat_params(mat), emitted, cn);
 }
 
 template <bool MOVING, int SPEC>

@@ -249,6 +249,7 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     for (uint32_t i = 0; i < s->n_textures; i++) {
         const RtwTexture &t = s->textures[i];
         if (t.row == 0 || t.col == 0 || (uint64_t)t.texel_offset + (uint64_t)t.row * t.col > s->n_texels) return RTW_E_INVALID;
+        if (t.emit_tex > s->n_textures) return RTW_E_INVALID;        // 1 + index of Rust2's emission image, 0 = none
     }
     HIP_TRY(hipSetDevice(c->device));
     free_scene(c);

@@ -46,6 +46,8 @@ def lib():
         L.rtw_oracle_rng_seed.restype = None
         L.rtw_oracle_rng_next.argtypes = [C.POINTER(C.c_uint32)]
         L.rtw_oracle_rng_next.restype = C.c_float
+        L.rtw_oracle_rust2_texel_index.argtypes = [C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_int]
+        L.rtw_oracle_rust2_texel_index.restype = C.c_uint32
         L.rtw_oracle_rotated.argtypes = [fp, fp, fp]
         L.rtw_oracle_rotated.restype = None
         _lib = L

@@ -1,0 +1,84 @@
+"""Round-3 CPU tests: Rust2's ImageTexture::color_at rule in the oracle, the image-level check of the sample stream
+(the truncated LCG against the old RXS-M-XS permuted stream), host logic of the guided unit lengths."""
+import numpy as np
+import pytest
+
+import rtw_amd as R
+from tests import oracle_binding as O
+from tests.test_oracle_golden import flag_params
+
+
+# ---- a10: Rust2's ImageTexture::color_at (Rust2/src/objects/texture.rs:94-105) ---------------------------------------------------------
+def test_rust2_texel_index_known_answers():
+    """Hand-computed from the reference's lines:
+         let x = (x * self.width as f32) as usize; let y = (y * self.height as f32) as usize;   multiplied: self.img[x * self.width + y]
+         let emmit_x = (x * self.emmit_width as f32).floor() as usize; ...                      emmited: self.emmit_img[emmit_x * self.emmit_width + emmit_y]
+    -- scaled by the SIZE (Rust/ scales by size - 1) and indexed x * width + y (Rust/: y * row + x)."""
+    idx = O.lib().rtw_oracle_rust2_texel_index
+    # width 4, height 2 (8 texels)
+    assert idx(0.3, 0.6, 4, 2, 0) == 1 * 4 + 1          # x = (1.2) as usize = 1, y = (1.2) as usize = 1  -> 5   (the Rust/ rule: floor(.3*3) + 4*floor(.6*1) = 0)
+    assert idx(0.0, 0.0, 4, 2, 0) == 0
+    assert idx(0.2, 0.9, 4, 2, 0) == 0 * 4 + 1          # x = 0, y = (1.8) -> 1: texel 1 -- the SECOND COLUMN of the first row in memory: transposed
+    assert idx(0.26, 0.1, 4, 2, 0) == 1 * 4 + 0         # x = (1.04) -> 1, y = 0 -> 4: the first texel of the second ROW in memory
+    assert idx(0.49, 0.49, 4, 2, 0) == 1 * 4 + 0
+    # x * width + y leaves the 8-texel image for u >= 0.5 (x >= 2): the reference panics there (index out of bounds); clamped to the last texel
+    assert idx(0.5, 0.0, 4, 2, 0) == 7 and idx(0.99, 0.99, 4, 2, 0) == 7 and idx(1.0, 1.0, 4, 2, 0) == 7
+    # a square image: every (x, y) with u, v < 1 is inside; the lookup is the transpose of the row-major one
+    assert idx(0.7, 0.2, 8, 8, 0) == 5 * 8 + 1          # x = (5.6) -> 5, y = (1.6) -> 1
+    assert idx(0.2, 0.7, 8, 8, 0) == 1 * 8 + 5
+    # the emission image: floor() before the cast -- the same index for the non-negative u, v of a sphere
+    assert idx(0.7, 0.2, 8, 8, 1) == 41 and idx(0.3, 0.6, 4, 2, 1) == 5
+    # negative / NaN coordinates: `as usize` saturates to 0
+    assert idx(-0.5, float("nan"), 4, 2, 0) == 0
+
+
+def rust2_texture_scene(emission=True):
+    """One unit sphere with a 4 x 4 image (every texel a different colour) + an 8 x 8 emission image, and a small Lambertian sphere beside it."""
+    w = h = 4
+    img = np.zeros((h, w, 3), np.float32)
+    for j in range(h):
+        for i in range(w):
+            img[j, i] = (0.1 + 0.2 * i, 0.1 + 0.2 * j, 0.5)
+    emit = np.zeros((8, 8, 3), np.float32)
+    for j in range(8):
+        for i in range(8):
+            emit[j, i] = (0.01 * i, 0.01 * j, 0.0)
+    big = R.Sphere.new_with_texture((0.0, 0.0, -2.0), 1.0, None, R.SCATTER_M, 0)
+    for k in range(3):
+        big.pod.col_mod[k] = 1.0
+    small = R.Sphere.with_albedo((1.6, 0.0, -1.6), 0.4, (0.8, 0.8, 0.8), R.SCATTER_M)
+    scene = R.Scene([big, small], textures=[img, emit], background=(1.0, 1.0, 1.0), emission_images={0: 1} if emission else None)
+    return scene, img, emit
+
+
+def test_rust2_image_texture_in_the_oracle():
+    """Depth 1, no random sampling: pixel = emmited + background * multiplied = the two texels the lookup chose.  The chosen texels follow
+    Rust2's transposed rule -- checked against the normal of the traced ray in f64 -- and differ from what the Rust/ rule picks."""
+    scene, img, emit = rust2_texture_scene()
+    p = flag_params(depth=1)
+    p.integrator, p.maxt = R.INTEGRATOR_RUST2, 1000.0
+    flat, eflat = img.reshape(-1, 3), emit.reshape(-1, 3)
+    checked = transposed_matters = 0
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        d = np.float32([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), -1.0])
+        rec, rgb = O.trace_ray((0.0, 0.0, 0.0), d, 0.0, scene, p, 0, 0)
+        if not rec or not rec[0].hit or rec[0].sphere != 0:
+            continue
+        n = np.float64(list(rec[0].normal))
+        u = (np.arctan2(-n[2], n[0]) + np.pi) / (2 * np.pi)
+        v = 1.0 - np.arccos(-n[1]) / np.pi
+        if min(abs(u * 4 - round(u * 4)), abs(v * 4 - round(v * 4)), abs(u * 8 - round(u * 8)), abs(v * 8 - round(v * 8))) < 1e-3:
+            continue                                                   # too close to a texel edge for an f64 re-derivation
+        x, y = int(u * 4), int(v * 4)
+        ex, ey = int(np.floor(u * 8)), int(np.floor(v * 8))
+        want = eflat[min(ex * 8 + ey, 63)] + np.float32(1.0) * flat[min(x * 4 + y, 15)]
+        assert np.array_equal(np.float32(rgb), np.float32(want)), (u, v, rgb, want)
+        checked += 1
+        rust1 = flat[int(np.floor(v * 3)) * 4 + int(np.floor(u * 3))]      # sphere.rs:137-138 + texture.rs:265
+        transposed_matters += not np.array_equal(flat[min(x * 4 + y, 15)], rust1)
+    assert checked > 100 and transposed_matters > 50
+    # without an emission image the sphere's constant `emitted` is used
+    scene2, _, _ = rust2_texture_scene(emission=False)
+    rec, rgb = O.trace_ray((0.0, 0.0, 0.0), np.float32([0.1, 0.2, -1.0]), 0.0, scene2, p, 0, 0)
+    assert rec[0].hit and any(np.array_equal(np.float32(rgb), t) for t in flat)
