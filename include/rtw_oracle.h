@@ -18,6 +18,11 @@
 extern "C" {
 #endif
 
+/* Oracle-only, test-only bit of RtwParams.flags: draw through PCG's RXS-M-XS output permutation (the stream of rounds 1 - 2a) instead of taking
+ * the top 24 bits of the LCG state directly (the product's stream).  Exists for the image-level comparison of the two streams; the device
+ * ignores the bit (it has no such stream). */
+#define RTW_ORACLE_FLAG_PERMUTED_STREAM 0x40000000u
+
 /* Same contract as rtw_ctx_render(); `threads` row-parallel workers (one task per row, like
  * tokio::spawn(render_row) viewport.rs:236-240), threads <= 1 runs serially. */
 int rtw_oracle_render(const RtwCamera *cam, const RtwScene *scene, const RtwParams *params,

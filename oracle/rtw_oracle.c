@@ -79,7 +79,7 @@ static inline int v3_close_to_zero(v3 a) { return fabsf(a.x) < 1e-7f && fabsf(a.
  * draw were 9 % of the frame -- DESIGN.md "RNG" -- and tests/test_rng_quality.py finds nothing they
  * bought for streams this short and this well separated.)
  * ---------------------------------------------------------------------------------------------- */
-typedef struct { uint32_t state, inc; } rng_t;
+typedef struct { uint32_t state, inc; uint32_t permuted; } rng_t;   /* permuted: RTW_ORACLE_FLAG_PERMUTED_STREAM (test-only, see rng_u32) */
 
 static inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -90,12 +90,18 @@ static inline rng_t rng_seed(uint64_t seed, uint32_t pixel, uint32_t sample) {
     h = mix32(h ^ (uint32_t)(seed >> 32));
     h = mix32(h ^ pixel);
     h = mix32(h ^ sample);
-    rng_t r; r.state = h; r.inc = mix32(h ^ 0x85EBCA6BU) | 1U;
+    rng_t r; r.state = h; r.inc = mix32(h ^ 0x85EBCA6BU) | 1U; r.permuted = 0;
     return r;
 }
 static inline uint32_t rng_u32(rng_t *r) {
     uint32_t old = r->state;
     r->state = old * 747796405U + r->inc;
+    if (r->permuted) {       /* TEST ONLY: the RXS-M-XS output stage of PCG that ran on top of the same LCG until the middle of round 2 (DESIGN.md "RNG"),
+                              * kept so that tests can compare IMAGES rendered with and without it (tests/test_round3_cpu.py); the device never had a
+                              * switch for it and the product stream is the plain one */
+        uint32_t word = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
+        return (word >> 22u) ^ word;
+    }
     return old;
 }
 static inline float rng_f32(rng_t *r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
@@ -105,7 +111,7 @@ void rtw_oracle_rng_seed(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_
     state[0] = r.state; state[1] = r.inc;
 }
 float rtw_oracle_rng_next(uint32_t state[2]) {
-    rng_t r; r.state = state[0]; r.inc = state[1];
+    rng_t r; r.state = state[0]; r.inc = state[1]; r.permuted = 0;
     float f = rng_f32(&r);
     state[0] = r.state;
     return f;
@@ -755,7 +761,7 @@ static void render_pixel(const RtwCamera *cam, const RtwScene *sc, const RtwPara
     ctx_t c; memset(&c, 0, sizeof c); c.sc = sc; c.p = p; c.cn = cn;
 
     if (p->sampler == RTW_SAMPLER_NO_RAND) {                        /* viewport.rs:498-508 */
-        rng_t rng = rng_seed(p->seed, pixel, 0); c.rng = &rng;
+        rng_t rng = rng_seed(p->seed, pixel, 0); rng.permuted = (p->flags & RTW_ORACLE_FLAG_PERMUTED_STREAM) != 0; c.rng = &rng;
         ray_t r; r.origin = origin; r.time = 0.0f;
         r.dir = v3_add(v3_add(p00, v3_scale(du, (float)i)), v3_scale(dv, (float)j));
         v3 col = gamma_correct(ray_color(&c, r), inv_g);
@@ -764,7 +770,7 @@ static void render_pixel(const RtwCamera *cam, const RtwScene *sc, const RtwPara
         return;
     }
     for (uint32_t s = 0; s < n; s++) {
-        rng_t rng = rng_seed(p->seed, pixel, s); c.rng = &rng;
+        rng_t rng = rng_seed(p->seed, pixel, s); rng.permuted = (p->flags & RTW_ORACLE_FLAG_PERMUTED_STREAM) != 0; c.rng = &rng;
         ray_t r;
         if (p->sampler == RTW_SAMPLER_ROW) {                        /* viewport.rs:287-299 */
             v3 rp = random_in_unit_disk_s(&rng, (p->flags & RTW_FLAG_CPP_DIFFUSE) != 0);
@@ -895,7 +901,7 @@ int rtw_oracle_trace_ray(const float origin[3], const float dir[3], float time,
                          RtwOracleBounce *out, int cap, float rgb[3]) {
     if (!origin || !dir || !sc || !p) return RTW_E_INVALID;
     counters_t cn = { 0, 0, 0 };
-    rng_t rng = rng_seed(p->seed, pixel, sample);
+    rng_t rng = rng_seed(p->seed, pixel, sample); rng.permuted = (p->flags & RTW_ORACLE_FLAG_PERMUTED_STREAM) != 0;
     ctx_t c; memset(&c, 0, sizeof c); c.sc = sc; c.p = p; c.cn = &cn; c.rng = &rng;
     c.trace = out; c.trace_cap = cap;
     ray_t r; r.origin = v3_ld(origin); r.dir = v3_ld(dir); r.time = time;

@@ -104,3 +104,51 @@ def test_no_correlation_along_or_across_streams(streams):
         assert abs(np.corrcoef(grid[i, :, :-1].ravel(), grid[i, :, 1:].ravel())[0, 1]) < bound      # neighbouring samples of a pixel
         assert abs(np.corrcoef(grid[i, :-1, :].ravel(), grid[i, 1:, :].ravel())[0, 1]) < bound      # the same sample of neighbouring pixels
         assert abs(np.corrcoef(grid[i, :, :-1].ravel(), grid[i + 1, :, 1:].ravel())[0, 1]) < bound  # draw i of sample s, draw i + 1 of s + 1
+
+
+# ---- long streams: a depth-50 glass path draws hundreds of values from one stream --------------------------------------------
+@pytest.fixture(scope="module")
+def long_streams():
+    pix = np.repeat(np.arange(512, dtype=np.uint64) + 77000, 128)          # 512 pixels x 128 samples = 65536 streams
+    smp = np.tile(np.arange(128, dtype=np.uint64), 512)
+    st, inc = _seed(1, pix, smp)
+    return _draws(st, inc, 402)                                            # 402 draws = 134 consecutive triples per stream
+
+
+def test_long_streams_stay_uniform_at_every_depth(long_streams):
+    u = long_streams
+    n = u.shape[1]
+    for i in list(range(24, 402, 21)) + [399, 400, 401]:                   # 64 bins, 63 dof: 1 - 1e-6 quantile 140
+        assert _chi2(np.bincount((u[i] * 64).astype(int), minlength=64), n / 64) < 140.0, i
+    # pooled over all positions, fine bins: 4096 bins, 4095 dof: mean 4095, sd 90.5 -> 1 - 1e-6 at ~4540
+    pooled = np.bincount((u * 4096).astype(int).ravel(), minlength=4096)
+    assert _chi2(pooled, u.size / 4096) < 4540.0
+    # a stream's own mean over its 402 draws: sigma = 1 / sqrt(12 * 402); the worst of 65536 streams stays inside 5.5 sigma
+    assert np.abs(u.mean(axis=0) - 0.5).max() < 5.5 / np.sqrt(12.0 * 402)
+
+
+def test_fine_triples_pooled_over_draw_positions(long_streams):
+    """Consecutive triples in 32 x 32 x 32 cells (the rejection sampler's candidates), pooled over the 134 triple positions of 65536 streams:
+    8.8 M triples, 268 per cell, 32767 dof (mean 32767, sd 256: 1 - 1e-6 quantile ~33990).  A lattice structure of the LCG's triples coarser
+    than 1/32 of the cube would show here; every stream has its own increment, i.e. its own shift of the lattice."""
+    u = long_streams
+    t = (u.reshape(134, 3, -1) * 32).astype(np.int64)
+    cell = (t[:, 0] * 1024 + t[:, 1] * 32 + t[:, 2]).ravel()
+    counts = np.bincount(cell, minlength=32768)
+    assert _chi2(counts, cell.size / 32768) < 33990.0
+    # ... and the same for triples that straddle the sampler's phase (draws 1-3, 4-6, ... of a stream that first drew one value)
+    t = (u[1:400].reshape(133, 3, -1) * 32).astype(np.int64)
+    cell = (t[:, 0] * 1024 + t[:, 1] * 32 + t[:, 2]).ravel()
+    assert _chi2(np.bincount(cell, minlength=32768), cell.size / 32768) < 33990.0
+    # acceptance rate of the unit-ball test at every triple position: pi / 6
+    p = u.reshape(134, 3, -1) * 2.0 - 1.0
+    acc = ((p ** 2).sum(axis=1) <= 1.0).mean(axis=1)
+    assert np.abs(acc - np.pi / 6.0).max() < 5.0 * np.sqrt(0.25 / u.shape[1])
+
+
+def test_no_serial_correlation_deep_in_a_stream(long_streams):
+    u = long_streams
+    bound = 5.5 / np.sqrt(u.shape[1])
+    for i in (30, 101, 200, 333):
+        for lag in (1, 2, 3, 7, 64):
+            assert abs(np.corrcoef(u[i], u[i + lag])[0, 1]) < bound, (i, lag)
