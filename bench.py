@@ -196,7 +196,7 @@ def main():
         achieved = flop / k_s / 1e12
         # Counter evidence for this same command, from the committed rocprofv3 --pmc passes (scripts/profile_bench.sh +
         # scripts/summarise_profile.py): NOT measured in this run -- the source file is named in the line.
-        traffic, traffic_source, executed = None, None, None
+        traffic, traffic_source, executed, stale = None, None, None, None
         if world == 1 and not args.spp and args.accel == "bvh" and args.config == "c3" and not args.opt and not args.chunk_sums:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_rocprofv3_summary.json")))
@@ -204,6 +204,14 @@ def main():
                 prof = json.load(open(cands[-1]))
                 rel = os.path.relpath(cands[-1], ROOT)
                 pmc, der = prof.get("pmc", {}), prof.get("derived", {})
+                # The profile must be OF THIS KERNEL: its rocprofv3 kernel time (render + resolve) has to agree with this run's HIP-event time
+                # within 3 %, else the counters belong to another build and are not quoted.
+                prof_ms = der.get("render_kernel_avg_ms", 0.0) + der.get("resolve_kernel_avg_ms", 0.0)
+                stale = {"stale_profile": True, "profile": rel, "profile_kernel_ms": round(prof_ms, 3), "this_run_kernel_ms": round(k_s * 1e3, 3),
+                         "note": "the committed profile's kernel time differs from this run's by more than 3 %: traffic / executed_valu are not quoted"} \
+                    if not (prof_ms > 0.0 and abs(prof_ms - k_s * 1e3) <= 0.03 * k_s * 1e3) else None
+                if stale:
+                    der, pmc = {}, {}
                 if "hbm_bytes_per_step" in der:
                     traffic = der["hbm_bytes_per_step"]
                     traffic_source = f"{rel}: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, render + resolve, separate --pmc passes of this command"
@@ -232,7 +240,7 @@ def main():
                        "segments_per_camera_ray": round(seg / max(rays, 1), 4)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                         "executed_valu": executed,
+                         "executed_valu": executed, **({"stale_profile": stale} if stale else {}),
                          "kernel": "rtw::render_%s + rtw::resolve_kernel (timed together: HIP events around both)" % args.accel,
                          "kernel_ms": round(k_s * 1e3, 3),
                          "algorithmic_flop_per_launch": flop,

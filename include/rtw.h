@@ -41,6 +41,8 @@ extern "C" {
 #define RTW_E_UNSUPPORTED  -5   /* valid enum value that this build does not implement on the device */
 #define RTW_E_NO_SCENE     -6   /* rtw_ctx_render() before rtw_ctx_set_scene()                       */
 #define RTW_E_INTERNAL     -7   /* a render kernel gave up (safety valve of its persistent loop): the image is incomplete */
+#define RTW_E_RUNTIME_CONFLICT -8 /* rtw_ctx_create: two copies of the HIP runtime are loaded in this process (PyTorch imported after the
+                                     first rtw_* call): import torch first, see INTEGRATION.md.  v4 */
 
 /* ---- integrators: which `ray_color` closure the reference would have passed ----------------- */
 enum {
@@ -240,6 +242,7 @@ int         rtw_abi_version(void);
 int         rtw_device_count(void);
 const char *rtw_strerror(int status);
 int         rtw_last_hip_error(void);
+int         rtw_hip_runtime_count(void);   /* copies of libamdhip64 mapped into this process (1 is healthy; v4) */
 
 /* One context per GPU.  `device` is the HIP device ordinal. */
 int  rtw_ctx_create(int device, rtw_ctx **out);

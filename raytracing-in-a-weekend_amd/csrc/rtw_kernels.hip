@@ -193,7 +193,7 @@ static_assert(sizeof(RtwCamera) == 84 && offsetof(KArgs, cam) == 0, "start_path 
 __device__ __forceinline__ RtwCamera load_camera() {
     f16v lo; f8v hi;
     asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                 : "=s"(lo), "=s"(hi) : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
+                 : "=&s"(lo), "=&s"(hi) : "s"(__builtin_amdgcn_kernarg_segment_ptr()));      // (early-clobber: the first load's result must not land on the base pair the second still reads)
     RtwCamera c;
     c.origin[0] = lo[0]; c.origin[1] = lo[1]; c.origin[2] = lo[2]; c.u[0] = lo[3]; c.u[1] = lo[4]; c.u[2] = lo[5];
     c.v[0] = lo[6]; c.v[1] = lo[7]; c.v[2] = lo[8]; c.pixel00[0] = lo[9]; c.pixel00[1] = lo[10]; c.pixel00[2] = lo[11];

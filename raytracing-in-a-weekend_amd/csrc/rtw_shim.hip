@@ -4,6 +4,8 @@
 #include "rtw_kernels.h"
 #include "rtw_host.h"
 
+#include <link.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -146,9 +148,24 @@ static int upload(void **dst, const std::vector<T> &src) {
     return RTW_OK;
 }
 
+// How many copies of the HIP runtime are mapped into this process.  librtw_hip.so links /opt/rocm's libamdhip64; PyTorch ships its own.  When torch
+// is imported FIRST the dynamic linker gives this library the copy that is already loaded (same soname) and all is well; when this library is
+// loaded first, a later `import torch` brings up a SECOND runtime whose device enumeration fails ("No HIP GPUs are available",
+// gpurun_out/r02_debug_torch.log) -- torch is then blind for the rest of the process.  A context created in such a process fails loudly instead.
+static int count_hip_runtimes_cb(struct dl_phdr_info *info, size_t, void *data) {
+    if (info->dlpi_name && std::strstr(info->dlpi_name, "libamdhip64")) ++*(int *)data;
+    return 0;
+}
+
 extern "C" {
 
 int rtw_abi_version(void) { return RTW_ABI_VERSION; }
+
+int rtw_hip_runtime_count(void) {
+    int n = 0;
+    dl_iterate_phdr(count_hip_runtimes_cb, &n);
+    return n;
+}
 
 int rtw_last_hip_error(void) { return g_last_hip; }
 
@@ -168,6 +185,8 @@ const char *rtw_strerror(int status) {
     case RTW_E_UNSUPPORTED: return "not implemented on the device";
     case RTW_E_NO_SCENE: return "no scene set";
     case RTW_E_INTERNAL: return "a render kernel gave up (internal error): the image is incomplete";
+    case RTW_E_RUNTIME_CONFLICT: return "two copies of the HIP runtime (libamdhip64) are loaded in this process -- typically PyTorch imported AFTER the first rtw_* call: "
+                                        "import torch before using this library (the runtimes then share one copy), or link both against the same runtime";
     default: return "unknown status";
     }
 }
@@ -175,6 +194,7 @@ const char *rtw_strerror(int status) {
 int rtw_ctx_create(int device, rtw_ctx **out) {
     if (!out) return RTW_E_INVALID;
     *out = nullptr;
+    if (rtw_hip_runtime_count() > 1) return RTW_E_RUNTIME_CONFLICT;
     int n = rtw_device_count();
     if (n <= 0 || device < 0 || device >= n) return RTW_E_NO_DEVICE;
     rtw_ctx *c = new (std::nothrow) rtw_ctx();

@@ -428,3 +428,9 @@ def test_tile_order_modes_on_the_bench_frame():
     assert R.lib().rtw_tile_order(2, 1920, 1080, C.byref(cam2), C.byref(scene.pod), buf, n) == 0
     rows2 = np.array(buf[:]) // 240
     assert rows2[:2000].mean() < 35 and rows2[-2000:].mean() > 125                           # upside-down image: the near field is at the top now
+
+
+def test_one_hip_runtime_in_this_process():
+    """conftest imports torch before the library is loaded, so both share ONE copy of libamdhip64 (rtw_ctx_create refuses a process with two)."""
+    assert R.lib().rtw_hip_runtime_count() == 1
+    assert "libamdhip64" in R.lib().rtw_strerror(-8).decode() and "torch" in R.lib().rtw_strerror(-8).decode()

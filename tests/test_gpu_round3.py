@@ -114,3 +114,24 @@ def test_rust2_image_texture_on_the_gpu(gpu, shape):
         assert any(np.abs(px - t - e).max() < 1e-6 for t in flat for e in emit.reshape(-1, 3)), px
     O_ref, _ = O.render(cam, scene, p, threads=4)
     assert (ulp_diff(direct, O_ref) <= 2).all(axis=2).mean() > 0.995
+
+
+def test_second_hip_runtime_is_refused_loudly(gpu):
+    """PyTorch imported AFTER the first rtw_* call brings a second libamdhip64 into the process and is blind from then on ("No HIP GPUs are
+    available", gpurun_out/r02_debug_torch.log).  The library cannot stop torch from loading, but a context created in such a process fails
+    with RTW_E_RUNTIME_CONFLICT and a message that names the cause, instead of rendering next to a broken torch."""
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import rtw_amd as R\n"
+            "assert R.lib().rtw_hip_runtime_count() == 1\n"
+            "r = R.Renderer(0); r.close()\n"                       # fine: one runtime so far
+            "import torch\n"
+            "print('runtimes', R.lib().rtw_hip_runtime_count())\n"
+            "try:\n"
+            "    R.Renderer(0)\n"
+            "    print('created')\n"
+            "except R.RtwError as e:\n"
+            "    print('refused', e.status, e)\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "runtimes 2" in out.stdout and "refused -8" in out.stdout and "import torch before" in out.stdout, out.stdout
