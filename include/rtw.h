@@ -283,9 +283,13 @@ enum {
     RTW_OPT_TILE_ORDER       = 6, /* order in which the 8x8 tiles enter the work queue: 0 (default) raster; 1 groups of 8
                                      tiles scattered over the frame; 2 expensive tiles first by a cost estimated from each tile's centre
                                      ray (sphere field / ground only / sky, nearer first; raster for scenes with quads or instances);
-                                     3 reverse raster; 4 as 2 in 32 coarse steps per class, raster inside a step                      */
+                                     3 reverse raster; 4 as 2 in 32 coarse steps per class, raster inside a step; 5 raster inside each
+                                     class, classes in the order sphere field, bare ground, sky (v4; measured: no gain)                    */
     RTW_OPT_GRAB_BLOCKS      = 7, /* 64-item blocks of the work queue a wave may take with one atomic while plenty of work is left (single
                                      blocks towards the end of a launch): default 2; 1 = always one; 0 = up to one tile's blocks      */
+    RTW_OPT_TAIL_UNITS       = 9, /* guided unit length: the last tiles of the work queue are cut into units of ONE sample (k blocks of them per
+                                     resident wave, k = this value) and the tiles before them into units of a third of the launch's length;
+                                     0 (default) = one unit length for the whole launch.  Measured: no gain.  v4                 */
     RTW_OPT_SUB_QUEUES       = 8  /* 0 (default): the work queue is eight sub-queues with a counter each (a wave starts on the one of its
                                      XCD and helps out on the others when it is empty), a single one for tiny launches; 1: always single */
 };

@@ -38,6 +38,7 @@ ACCEL_BRUTE, ACCEL_BVH = 0, 1
 FLAG_RECURSIVE_ORDER, FLAG_CPP_DIELECTRIC, FLAG_GLOBAL_NODES, FLAG_CPP_DIFFUSE, FLAG_CHUNK_SUMS = 1, 2, 4, 8, 16
 FLAG_CPP = FLAG_CPP_DIELECTRIC | FLAG_CPP_DIFFUSE      # what Viewport::RenderGPU of the C++ tree asks for
 OPT_CHUNK_LEN, OPT_SAMPLE_BANK_GB, OPT_LDS_GEOM, OPT_BLOCKS_PER_CU, OPT_LIST_WALK_MAX, OPT_TILE_ORDER, OPT_GRAB_BLOCKS, OPT_SUB_QUEUES = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_TAIL_UNITS = 9
 SCENE_C1, SCENE_C2, SCENE_C4, SCENE_C5, SCENE_METAL_TEST, SCENE_QUAD_TEST, SCENE_PRESENTATION, SCENE_FIRST_FRAME = 1, 2, 4, 5, 6, 7, 8, 9
 MEDIUM_SURFACE, MEDIUM_CONST_DENSITY = 0, 1
 

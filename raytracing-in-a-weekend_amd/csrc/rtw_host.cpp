@@ -728,14 +728,14 @@ void build_tile_order(uint32_t mode, uint32_t tiles_x, uint32_t tiles_y, uint32_
     const uint32_t n = tiles_x * tiles_y;
     order.resize(n);
     if (mode == 3u) { for (uint32_t q = 0; q < n; q++) order[q] = n - 1u - q; return; }
-    if (mode != 1u && mode != 2u && mode != 4u) { for (uint32_t q = 0; q < n; q++) order[q] = q; return; }
+    if (mode != 1u && mode != 2u && mode != 4u && mode != 5u) { for (uint32_t q = 0; q < n; q++) order[q] = q; return; }
     const uint32_t g = 8u, ng = (n + g - 1u) / g;      // (group sizes 2..64 measure the same within noise: profiles/r02_tile_order.log)
     const std::vector<uint32_t> grp = scatter_perm(ng);
     uint32_t k = 0;
     for (uint32_t q = 0; q < ng; q++)
         for (uint32_t i = 0; i < g; i++) { const uint32_t t = grp[q] * g + i; if (t < n) order[k++] = t; }
-    if ((mode != 2u && mode != 4u) || cull.n_other || (!cull.has_tree && !cull.n_big)) {
-        if (mode == 4u) for (uint32_t q = 0; q < n; q++) order[q] = q;          // (no cost guess: raster)
+    if ((mode != 2u && mode != 4u && mode != 5u) || cull.n_other || (!cull.has_tree && !cull.n_big)) {
+        if (mode == 4u || mode == 5u) for (uint32_t q = 0; q < n; q++) order[q] = q;          // (no cost guess: raster)
         return;
     }
     // Mode 2: longest-processing-time-first by an ESTIMATE of a tile's cost, from its centre ray (no lens offset, no jitter):
@@ -765,6 +765,14 @@ void build_tile_order(uint32_t mode, uint32_t tiles_x, uint32_t tiles_y, uint32_
         else if (big < 1e300) { kx.cls = 1; kx.dist = (float)big; }
         if (!(kx.dist == kx.dist)) kx.dist = 0.0f;           // (degenerate cameras)
         keys[t] = kx;
+    }
+    if (mode == 5u) {
+        // Mode 5: raster order inside each class, the classes in the order sphere field, bare ground, sky.  What ends a launch is the longest PATH
+        // that starts late (profiles/r03_endtimes.log: with units of one sample at the end of the queue a wave still runs on for 0.3 ms on average and
+        // 1.1 ms at most after the queue is empty -- a 50-bounce glass path at seven busy waves per SIMD); a tile of sky holds no such path.
+        std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.cls > b.cls; });
+        for (uint32_t q = 0; q < n; q++) order[q] = keys[q].tile;
+        return;
     }
     std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.cls != b.cls ? a.cls > b.cls : a.dist < b.dist; });
     if (mode == 4u) {

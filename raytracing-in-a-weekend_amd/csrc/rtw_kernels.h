@@ -44,13 +44,19 @@ struct KArgs {
     uint32_t width, height;       // full image
     uint32_t k_base, k_end;       // compact rows [k_base, k_end) of this partition rendered by this launch (a band)
     uint32_t n_tiles;             // tiles_x * ceil((k_end - k_base) / 8)
-    uint32_t chunk_len, n_chunks; // samples per work unit, units per pixel
-    uint32_t bank_len;            // bank slots per unit and pixel: chunk_len (one per sample), or 1 with RTW_FLAG_CHUNK_SUMS
+    uint32_t chunk_len, n_chunks; // samples per work unit and units per pixel of the queue's FIRST region (all of it with RTW_FLAG_CHUNK_SUMS)
+    uint32_t bank_len;            // 0: the bank holds one slot per sample, [tile][sample][pixel] -- independent of how the samples are cut into units;
+                                  // 1 (RTW_FLAG_CHUNK_SUMS): one slot per unit, [tile][chunk][pixel]
+    // The unit length is GUIDED within a launch: the tiles at queue positions [0, reg_q1) are cut into units of reg_len[0] samples, [reg_q1, reg_q2) into
+    // units of reg_len[1], the rest -- the end of the queue -- into units of reg_len[2] (reg_nc[r] = ceil(n_samples / reg_len[r]) units per pixel):
+    // long units amortise the per-unit work while plenty is left, short ones keep the drain of the launch short (rtw_shim.hip)
+    uint32_t reg_q1, reg_q2;
+    uint32_t reg_len[3], reg_nc[3];
     uint32_t flags;               // RtwParams.flags (RTW_FLAG_CPP_*: generic build only)
-    float *samples;               // per-sample radiance, [n_tiles * n_chunks][bank_len][64][3]
+    float *samples;               // per-sample radiance, [n_tiles][n_samples][64][3]  (RTW_FLAG_CHUNK_SUMS: [n_tiles][n_chunks][64][3])
     uint32_t row_block, part_index, part_count;
     uint32_t tiles_x;             // ceil(width / 8)
-    uint32_t total_work;          // 64 * n_tiles * n_chunks
+    uint32_t total_work;          // work items of the launch: 64 per (tile, unit)
     uint32_t sub_shift;           // the work queue is 2^sub_shift sub-queues (tiles dealt round-robin in queue order), counters RTW_QUEUE_STRIDE bytes apart
     uint32_t grab_shift, grab_max;   // a wave takes min(grab_max, (work left >> grab_shift) rounded down to whole blocks, at least one block) items per queue atomic
     const uint32_t *tile_order;   // queue position -> tile (a permutation of [0, n_tiles)), or null = raster order

@@ -82,7 +82,7 @@ struct Reserve {                             // wave-uniform
     uint32_t sub, tries;                     // the sub-queue this wave takes from, and how many sub-queues it has found empty
     uint32_t i0, k0;                         // the block's tile: first column, first compact row
     uint32_t s0, s1;                         // the block's chunk: samples [s0, s1)
-    uint32_t unit;                           // tile * n_chunks + chunk: the block's place in the sample bank
+    uint32_t slot0;                          // the block's place in the sample bank: slot of (its tile, its first sample, pixel 0)
 #ifdef RTW_ENDTIMES
     unsigned long long t_dry;                // diagnostic build: device-wide time at which this wave first found the queue empty (0: not yet)
 #endif
@@ -92,6 +92,19 @@ struct Reserve {                             // wave-uniform
 // that are currently active; returns true for lanes that got a valid unit.  `exhausted` is set for
 // lanes that found the queue empty.  Lanes that get nothing (reserve ran out mid-way, padding pixel)
 // simply ask again on the next trip.
+// Sub-queue `sub` holds the tiles at queue positions sub, sub + S, .. (S = 2^sub_shift); its blocks are numbered tile by tile, a tile's units in
+// sample order.  With the three regions of unit length: t1 / t2 = its tiles in region 1 / regions 1 + 2, b1 / b2 = the blocks before region 2 / 3.
+struct SubQ { uint32_t t1, t2, b1, b2, total; };
+__device__ __forceinline__ SubQ subq_layout(const KArgs &A, uint32_t sub) {
+    const uint32_t up = (1u << A.sub_shift) - 1u - sub;            // (x + up) >> sub_shift = the queue positions below x that belong to this sub-queue
+    SubQ q;
+    q.t1 = (A.reg_q1 + up) >> A.sub_shift; q.t2 = (A.reg_q2 + up) >> A.sub_shift;
+    const uint32_t t3 = (A.n_tiles + up) >> A.sub_shift;
+    q.b1 = q.t1 * A.reg_nc[0]; q.b2 = q.b1 + (q.t2 - q.t1) * A.reg_nc[1];
+    q.total = (q.b2 + (t3 - q.t2) * A.reg_nc[2]) * 64u;
+    return q;
+}
+
 __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px, bool &exhausted, Reserve &rs) {
     const unsigned long long m = __ballot(need);
     if (m == 0ull) return false;
@@ -114,7 +127,7 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
             const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
             bool got = false;
             while (rs.tries < n_sub) {                            // (wave-uniform; at most n_sub failed grabs in a wave's life)
-                const uint32_t total = ((A.n_tiles + n_sub - 1u - rs.sub) >> A.sub_shift) * A.n_chunks * 64u;   // items of sub-queue rs.sub
+                const uint32_t total = subq_layout(A, rs.sub).total;     // items of sub-queue rs.sub
                 uint32_t grab = 64u;
                 if (rs.tries == 0u && rs.limit < total) {
                     grab = ((total - rs.limit) >> A.grab_shift) & ~63u;
@@ -142,17 +155,23 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
         if (rs.next < rs.limit) {
             // Work unit = (8x8 tile, chunk of chunk_len samples, pixel of the tile); the units of one tile are consecutive.  The
             // block's tile and chunk are the same for its 64 items: the three integer divisions run once per block, here.
-            const uint32_t u = rs.next >> 6;                       // block of the sub-queue
-            const uint32_t lt = u / A.n_chunks, chunk = u - lt * A.n_chunks;
+            // The unit length depends on where in the queue the tile sits (KArgs.reg_*): three regions, so three cases of the same division.
+            uint32_t u = rs.next >> 6;                             // block of the sub-queue
+            const SubQ sq = subq_layout(A, rs.sub);
+            uint32_t lt, chunk, len;
+            if (u < sq.b1) { lt = u / A.reg_nc[0]; chunk = u - lt * A.reg_nc[0]; len = A.reg_len[0]; }
+            else if (u < sq.b2) { u -= sq.b1; lt = u / A.reg_nc[1]; chunk = u - lt * A.reg_nc[1]; lt += sq.t1; len = A.reg_len[1]; }
+            else { u -= sq.b2; lt = u / A.reg_nc[2]; chunk = u - lt * A.reg_nc[2]; lt += sq.t2; len = A.reg_len[2]; }
             const uint32_t qt = (lt << A.sub_shift) + rs.sub;      // ... -> queue position of its tile
             // queue position -> tile: raster order, or any permutation the host supplies (RTW_OPT_TILE_ORDER)
             const uint32_t tile = A.tile_order ? A.tile_order[qt] : qt;
-            rs.unit = tile * A.n_chunks + chunk;
             const uint32_t trow = tile / A.tiles_x, tcol = tile - trow * A.tiles_x;
             rs.i0 = tcol * 8u;
             rs.k0 = A.k_base + trow * 8u;
-            rs.s0 = chunk * A.chunk_len;
-            rs.s1 = rs.s0 + A.chunk_len < A.n_samples ? rs.s0 + A.chunk_len : A.n_samples;
+            rs.s0 = chunk * len;
+            rs.s1 = rs.s0 + len < A.n_samples ? rs.s0 + len : A.n_samples;
+            // [tile][sample][pixel] -- or, one partial sum per unit (RTW_FLAG_CHUNK_SUMS: a single region), [tile][chunk][pixel]
+            rs.slot0 = (A.bank_len ? tile * A.n_chunks + chunk : tile * A.n_samples + rs.s0) * 64u;
         }
     }
     const uint32_t avail = rs.end - rs.next;
@@ -176,8 +195,8 @@ __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px
     px.ij = i | (j << 16);
     px.rng_base = rng_pixel_base(A.seed_lo, A.seed_hi, j * A.width + i);
     px.s = rs.s0 | ((rs.s1 - rs.s0) << 24);
-    px.slot = rs.unit * 64u * A.bank_len + (w & 63u);            // [unit][sample of chunk][pixel of tile]: lanes that finish the same
-                                                                   // sample of neighbouring pixels together fill whole sectors
+    px.slot = rs.slot0 + (w & 63u);                              // [tile][sample][pixel of tile]: lanes that finish the same sample of neighbouring
+                                                                   // pixels together fill whole sectors
     return rs.s0 < rs.s1;
 }
 
@@ -395,7 +414,7 @@ __device__ __forceinline__ bool finish_path(const KArgs &A, Pixel &px, Path &pt,
 
 // The pixel stage of the driver (viewport.rs:299-301): color = sum of the samples IN ORDER, / samples,
 // powf(1/gamma), one coalesced-by-tile 12-byte store per pixel.  One lane per pixel; the per-sample radiances
-// were banked by the render kernel as [unit = tile*n_chunks + chunk][sample of chunk][pixel of tile].
+// were banked by the render kernel as [tile][sample][pixel of tile].
 __global__ __launch_bounds__(RTW_BLOCK) void resolve_kernel(const KArgs A) {
     const uint32_t w = blockIdx.x * RTW_BLOCK + threadIdx.x;
     const uint32_t tile = w >> 6, p = w & 63u;
@@ -405,14 +424,10 @@ __global__ __launch_bounds__(RTW_BLOCK) void resolve_kernel(const KArgs A) {
         const uint32_t i = tcol * 8u + (p & 7u), k = A.k_base + trow * 8u + (p >> 3);
         if (i < A.width && k < A.k_end) {
             v3 acc = mk(0, 0, 0);
-            uint32_t s = 0;
-            for (uint32_t c = 0; c < A.n_chunks; c++) {
-                const float *src = A.samples + 3 * ((size_t)(tile * A.n_chunks + c) * 64u * A.bank_len + p);
-                const uint32_t cnt = s + A.chunk_len < A.n_samples ? A.chunk_len : A.n_samples - s;
-                // (RTW_FLAG_CHUNK_SUMS: bank_len == 1, the slot already holds the chunk's sum)
-                for (uint32_t q = 0; q < (A.bank_len == 1u ? 1u : cnt); q++) acc = acc + ld3(src + 3 * 64u * q);     // viewport.rs:299
-                s += cnt;
-            }
+            // one slot per sample, in sample order -- however the render kernel cut them into units -- or (RTW_FLAG_CHUNK_SUMS) one per unit
+            const uint32_t n_slots = A.bank_len ? A.n_chunks : A.n_samples;
+            const float *src = A.samples + 3 * ((size_t)tile * n_slots * 64u + p);
+            for (uint32_t q = 0; q < n_slots; q++) acc = acc + ld3(src + 3 * 64u * (size_t)q);     // viewport.rs:299
             v3 col = acc / (float)A.n_samples;                   // viewport.rs:301
             // gamma_correct (viewport.rs:207-213).  x^1 is x: skipping the libm call keeps the gamma == 1
             // output bit-identical to the CPU (ocml powf is not exact there).
@@ -507,7 +522,7 @@ template <bool MOVING, int SPEC, bool GEOM>
 __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_GEOM_BRUTE_WAVES : 1) void render_brute(const KArgs A) {
     bool dead = false, have = false, newpath = false;
     Pixel px; px.ij = px.rng_base = px.s = px.slot = 0;
-    Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = rs.tries = 0; rs.sub = blockIdx.x & ((1u << A.sub_shift) - 1u);
+    Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.slot0 = rs.tries = 0; rs.sub = blockIdx.x & ((1u << A.sub_shift) - 1u);
 #ifdef RTW_ENDTIMES
     rs.t_dry = 0ull;
 #endif
@@ -868,7 +883,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
                       F_K_SHIFT = 8u };  // specialised builds: the path's bounce count (Path.k) in bits 8..31
     uint32_t fl = 0u;
     Pixel px; px.ij = px.rng_base = px.s = px.slot = 0;
-    Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.unit = rs.tries = 0; rs.sub = blockIdx.x & ((1u << A.sub_shift) - 1u);
+    Reserve rs; rs.next = rs.end = rs.limit = rs.i0 = rs.k0 = rs.s0 = rs.s1 = rs.slot0 = rs.tries = 0; rs.sub = blockIdx.x & ((1u << A.sub_shift) - 1u);
 #ifdef RTW_ENDTIMES
     rs.t_dry = 0ull;
 #endif

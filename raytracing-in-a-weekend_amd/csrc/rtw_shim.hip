@@ -70,6 +70,8 @@ struct rtw_ctx {
                                          // r02_order_chunk_grid.log --; with today's units and grabs raster is 1.2 % ahead of it on the bench frame and ahead
                                          // on every other config too, profiles/r02_order_ab.log)
     uint32_t opt_sub_queues = 0;         // RTW_OPT_SUB_QUEUES: 0 = eight sub-queues (one per XCD) for all but tiny launches, 1 = a single queue
+    double opt_tail_units = 0.0;         // RTW_OPT_TAIL_UNITS: blocks of short units per resident wave at the end of the queue (render_enqueue); 0 = off.
+                                         // OFF by default: measured, it does not shorten a launch (profiles/r03_tail_units.log, r03_endtimes.log)
     uint32_t opt_grab_blocks = 2;        // RTW_OPT_GRAB_BLOCKS (profiles/r02_grab_sweep.log: 1 / 2 / 4 / 8 / a tile's 42 blocks = 83.9 / 82.9 / 83.7 / 86.8 / 107.9 ms on the bench frame)
 
     // cache of a per-call driver query (tens of microseconds: visible on small frames)
@@ -472,7 +474,8 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     // so that no lane owns more than chunk_len sequential paths (the slowest PIXEL used to set a ~50 ms tail).
     // Every sample's radiance is banked in HBM and added in order by resolve_kernel: 12 B per camera ray
     // (12.4 GB for 1920x1080x500) -- the image is rendered in bands of tile rows when that exceeds the budget.
-    // RTW_FLAG_CHUNK_SUMS banks one partial sum per unit instead (bank_len = 1 slot per unit and pixel).
+    // RTW_FLAG_CHUNK_SUMS banks one partial sum per unit instead (bank_len = 1: one slot per unit and pixel).
+    const bool sums = (p->flags & RTW_FLAG_CHUNK_SUMS) != 0;
     uint32_t chunk_len = (p->flags & RTW_FLAG_CHUNK_SUMS) ? RTW_SUM_CHUNK : c->opt_chunk_len;   // (the summation chunk is part of the image's definition)
     if (chunk_len == 0) {
         // auto: the unit length follows the size of the launch (profiles/r02_order_chunk_grid.log).  Long units amortise the per-unit work
@@ -488,11 +491,12 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
     if (chunk_len > a.n_samples) chunk_len = a.n_samples;
     a.chunk_len = chunk_len;
     a.n_chunks = (a.n_samples + chunk_len - 1) / chunk_len;
-    a.bank_len = (p->flags & RTW_FLAG_CHUNK_SUMS) ? 1u : chunk_len;
-    const uint64_t slots_per_tile_row = (uint64_t)a.tiles_x * a.n_chunks * 64ull * a.bank_len;
+    a.bank_len = sums ? 1u : 0u;
+    // the bank: one slot per (tile, sample, pixel) -- whatever the unit lengths --, or per (tile, unit, pixel) for the partial sums
+    const uint64_t slots_per_tile_row = (uint64_t)a.tiles_x * (sums ? a.n_chunks : a.n_samples) * 64ull;
     uint64_t max_slots = c->opt_bank_bytes / 12; if (max_slots > 0xFFFFFFF0ull) max_slots = 0xFFFFFFF0ull;
-    // (work items are counted in 32 bits as well: 64 per tile and chunk)
-    const uint64_t items_per_tile_row = (uint64_t)a.tiles_x * a.n_chunks * 64ull;
+    // (work items are counted in 32 bits as well: 64 per tile and unit, at most one unit per sample)
+    const uint64_t items_per_tile_row = slots_per_tile_row;
     const uint32_t tile_rows = (n_rows + 7) / 8;
     uint64_t band_tile_rows = max_slots / (slots_per_tile_row ? slots_per_tile_row : 1);
     if (band_tile_rows > 0xFFFFFFF0ull / items_per_tile_row) band_tile_rows = 0xFFFFFFF0ull / items_per_tile_row;
@@ -587,9 +591,11 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         const uint32_t tr1 = tr0 + (uint32_t)band_tile_rows < tile_rows ? tr0 + (uint32_t)band_tile_rows : tile_rows;
         a.k_base = tr0 * 8; a.k_end = tr1 * 8 < n_rows ? tr1 * 8 : n_rows;
         a.n_tiles = a.tiles_x * (tr1 - tr0);
-        a.total_work = a.n_tiles * a.n_chunks * 64u;              // < 2^32 by the item bound above
+        a.total_work = a.n_tiles * a.n_chunks * 64u;              // < 2^32 by the item bound above  (one region; refined below)
+        a.reg_q1 = a.reg_q2 = a.n_tiles;
+        for (int r = 0; r < 3; r++) { a.reg_len[r] = a.chunk_len; a.reg_nc[r] = a.n_chunks; }
         a.tile_order = nullptr;
-        if (c->opt_tile_order && a.n_tiles > 2u && !(c->opt_tile_order == 2u && c->cull.n_other)) {    // (quads / instances: no cost guess, raster order)
+        if (c->opt_tile_order && a.n_tiles > 2u && !((c->opt_tile_order == 2u || c->opt_tile_order == 5u) && c->cull.n_other)) {    // (quads / instances: no cost guess, raster order)
             // queue order of the tiles (rtw_host.cpp build_tile_order): built once per (mode, frame shape, camera, partition, scene), kept on the device
             const uint32_t tiles_y = a.n_tiles / a.tiles_x;
             TileOrderKey key;
@@ -631,8 +637,32 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
             if (wg_per_cu > 6u && (uint64_t)a.total_work < 40ull * c->n_cu * RTW_BLOCK * wg_per_cu) wg_per_cu = 6u;
         }
         uint32_t grid = (uint32_t)c->n_cu * wg_per_cu;
-        const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
-        if (grid > need) grid = need ? need : 1;
+        {
+            const uint32_t need = (a.total_work + RTW_BLOCK - 1) / RTW_BLOCK;
+            if (grid > need) grid = need ? need : 1;
+        }
+        // Guided unit length (RTW_OPT_TAIL_UNITS = k; 0, the default, = one length for the whole launch).  The idea: the end of a
+        // launch is one work unit deep per lane, so cut the LAST tiles of the queue into units of one sample and the tiles before them into units of
+        // a third of the launch's length -- region 3 holds k blocks of (tile, 1 sample) for every resident wave, region 2 k blocks of (tile, L2
+        // samples).  The image cannot change: the bank is indexed by (tile, sample, pixel) and the resolve adds in sample order.
+        // MEASURED (profiles/r03_tail_units.log, r03_endtimes.log, r03_tail_order.log): it does what it says -- a wave runs on for 0.31 instead of
+        // 0.40 ms on average after it finds the queue empty -- and gains nothing: an eighth of the bench frame 10.21 / 10.24 / 10.34 / 10.36 ms for
+        // k = 0 / 1 / 2 / 4, C2 7.07 / 7.09 / 7.00 / 7.13, the whole frame 74.48 / 74.64 / 74.71 / 74.66.  What a launch waits for at its end is not
+        // a unit but a PATH: with one-sample units the longest wait is still ~1.1 ms -- a 50-bounce glass path started just before the queue ran
+        // dry, at ~20 us per segment with seven busy waves per SIMD -- and a path cannot be split.  Handing the sky tiles out last so that no such
+        // path starts late (RTW_OPT_TILE_ORDER 5) does not help either.  Kept as an option; off.
+        if (!sums && c->opt_tail_units > 0.0 && a.chunk_len > 1u && a.n_tiles > 1u) {
+            const double waves = (double)grid * (RTW_BLOCK / 64u);
+            const uint32_t L1 = a.chunk_len, L2 = L1 >= 12u ? 4u : (L1 >= 6u ? 2u : 1u), L3 = 1u;
+            uint64_t t3 = (uint64_t)std::ceil(c->opt_tail_units * waves * L3 / (double)a.n_samples);
+            uint64_t t2 = L2 > L3 ? (uint64_t)std::ceil(c->opt_tail_units * waves * L2 / (double)a.n_samples) : 0;
+            if (t3 > a.n_tiles / 4u) t3 = a.n_tiles / 4u;                     // (small launches: at most a quarter of the tiles in either region)
+            if (t2 > a.n_tiles / 4u) t2 = a.n_tiles / 4u;
+            a.reg_q2 = a.n_tiles - (uint32_t)t3; a.reg_q1 = a.reg_q2 - (uint32_t)t2;
+            a.reg_len[1] = L2; a.reg_len[2] = L3;
+            for (int r = 1; r < 3; r++) a.reg_nc[r] = (a.n_samples + a.reg_len[r] - 1u) / a.reg_len[r];
+            a.total_work = (a.reg_q1 * a.reg_nc[0] + (a.reg_q2 - a.reg_q1) * a.reg_nc[1] + (a.n_tiles - a.reg_q2) * a.reg_nc[2]) * 64u;   // <= tiles x samples x 64 < 2^32
+        }
         {   // guided grabs (fetch_pixel): work left / (4 x resident waves), as a shift; at most RTW_OPT_GRAB_BLOCKS blocks (0: the blocks of one tile)
             a.sub_shift = (c->opt_sub_queues != 1u && a.n_tiles >= 64u && grid >= 64u) ? RTW_SUB_SHIFT : 0u;       // one sub-queue per XCD, unless the launch is tiny
             const uint32_t waves4 = (grid * (RTW_BLOCK / 64u) * 4u) >> a.sub_shift;
@@ -746,8 +776,9 @@ int rtw_ctx_set_option(rtw_ctx *c, uint32_t key, double v) {
     case RTW_OPT_LDS_GEOM:       if (!(v >= -1.0 && v <= 1.0)) return RTW_E_INVALID; c->opt_lds_geom = (int)v; return RTW_OK;
     case RTW_OPT_BLOCKS_PER_CU:  if (!(v >= 0.0 && v <= 8.0)) return RTW_E_INVALID; c->opt_blocks_per_cu = (uint32_t)v; return RTW_OK;
     case RTW_OPT_LIST_WALK_MAX:  if (!(v >= 0.0 && v <= 4294967295.0)) return RTW_E_INVALID; c->opt_list_walk_max = (uint32_t)v; return RTW_OK;
-    case RTW_OPT_TILE_ORDER:     if (!(v >= 0.0 && v <= 4.0 && v == (double)(uint32_t)v)) return RTW_E_INVALID; c->opt_tile_order = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_TILE_ORDER:     if (!(v >= 0.0 && v <= 5.0 && v == (double)(uint32_t)v)) return RTW_E_INVALID; c->opt_tile_order = (uint32_t)v; return RTW_OK;
     case RTW_OPT_SUB_QUEUES:     if (!(v == 0.0 || v == 1.0)) return RTW_E_INVALID; c->opt_sub_queues = (uint32_t)v; return RTW_OK;
+    case RTW_OPT_TAIL_UNITS:     if (!(v >= 0.0 && v <= 1024.0)) return RTW_E_INVALID; c->opt_tail_units = v; return RTW_OK;
     case RTW_OPT_GRAB_BLOCKS:    if (!(v >= 0.0 && v <= 65536.0 && v == (double)(uint32_t)v)) return RTW_E_INVALID; c->opt_grab_blocks = (uint32_t)v; return RTW_OK;
     default: return RTW_E_INVALID;
     }

@@ -135,3 +135,38 @@ def test_second_hip_runtime_is_refused_loudly(gpu):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "runtimes 2" in out.stdout and "refused -8" in out.stdout and "import torch before" in out.stdout, out.stdout
+
+
+# ---- the unit length may vary within a launch: the image may not ---------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [0.0, 0.5, 2.0, 64.0])
+def test_guided_unit_lengths_never_change_the_image(rtw, k):
+    """RTW_OPT_TAIL_UNITS cuts the last tiles of the queue into units of one sample and the ones before into shorter units than the rest; the
+    bank is indexed by (tile, sample, pixel) and the resolve adds in sample order, so full frames, banded renders, row partitions, a permuted
+    tile order and both kernels give the same bits, and every sample is traced exactly once."""
+    scene, cam, p = small_view(R.SCENE_C2, 320, 184, 40)
+    p.gamma, p.depth = 1.0, 6
+    with rtw.Renderer(0) as r:
+        r.set_scene(scene)
+        p.accel = R.ACCEL_BVH
+        ref, st_ref = r.render(cam, p)                                # one unit length (the default)
+        r.set_option(R.OPT_TAIL_UNITS, k)
+        for chunk in (0, 12, 5):
+            r.set_option(R.OPT_CHUNK_LEN, chunk)
+            for accel in (R.ACCEL_BVH, R.ACCEL_BRUTE):
+                p.accel = accel
+                img, st = r.render(cam, p)
+                assert st.camera_rays == 320 * 184 * 40 and st.segments == st_ref.segments and np.array_equal(img, ref), (k, chunk, accel)
+        p.accel = R.ACCEL_BVH
+        for order in (2, 5):
+            r.set_option(R.OPT_TILE_ORDER, order)
+            img, _ = r.render(cam, p)
+            assert np.array_equal(img, ref), order
+        r.set_option(R.OPT_TILE_ORDER, 0)
+        r.set_option(R.OPT_SAMPLE_BANK_GB, 0.01)                      # several bands of tile rows, each with its own regions
+        img, _ = r.render(cam, p)
+        assert np.array_equal(img, ref)
+        r.set_option(R.OPT_SAMPLE_BANK_GB, 48)
+        p.row_block, p.part_index, p.part_count = 8, 1, 3
+        part, _ = r.render(cam, p)
+        rows = [j for j in range(184) if (j // 8) % 3 == 1]
+        assert np.array_equal(part, ref[rows])
