@@ -23,6 +23,11 @@
 
 namespace rtw {
 
+// Lane mask of a predicate.  HIP's __ballot(int) compares the predicate, widened to an int, with zero: for a bool that lives in an SGPR pair (a
+// flag carried from a divergent branch) the compiler then materialises 0 / 1 in a VGPR and compares it again -- two VALU instructions of the slow class
+// for what is an s_and with exec.  The builtin takes the i1 itself.
+__device__ __forceinline__ unsigned long long ballot64(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+
 typedef float f4 __attribute__((ext_vector_type(4)));
 // Wave-uniform, read-only scene data is read through the constant address space so that hipcc emits
 // scalar loads (s_load_dwordx4 -> SGPR operands of the VALU ops) instead of 64 identical vector loads.
@@ -66,7 +71,7 @@ __device__ __forceinline__ float sqrt_plain(float x) {
 // sqrt(x), correctly rounded: the plain sequence when every active lane's x is in [2^-96, 2^127), hipcc's expansion otherwise (same bits)
 __device__ __forceinline__ float sqrt_ieee(float x) {
     const bool plain = (__float_as_uint(x) - 0x0F800000u) < (0x7F000000u - 0x0F800000u);
-    if (__ballot(!plain) == 0ull) return sqrt_plain(x);
+    if (ballot64(!plain) == 0ull) return sqrt_plain(x);
     return __builtin_sqrtf(x);
 }
 __device__ __forceinline__ float rcp_refined(float d) {
@@ -88,7 +93,7 @@ __device__ __forceinline__ float div_plain(float n, float d, float r) {
 __device__ __forceinline__ float sphere_root(float b, float disc, float a, float ra, bool a_plain, float mint) {
     const bool plain = (__float_as_uint(disc) - 0x21800000u) <= (0x6F800000u - 0x21800000u);      // 2^-60 <= disc <= 2^96
     float x;
-    if (a_plain && __ballot(!plain) == 0ull) {
+    if (a_plain && ballot64(!plain) == 0ull) {
         const float sq = sqrt_plain(disc);
         x = div_plain(-b - sq, a, ra);
         if (x < mint) x = div_plain(-b + sq, a, ra);
@@ -110,7 +115,7 @@ struct Cen { uint32_t n[CEN_N], w[CEN_N]; };
 #ifdef RTW_CENSUS
 __device__ __forceinline__ void cen_count(Cen *cn, int k) {
     if (!cn) return;
-    const unsigned long long m = __ballot(true);
+    const unsigned long long m = ballot64(true);
     cn->n[k]++;
     cn->w[k] += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u ? 1u : 0u;
 }
@@ -130,7 +135,7 @@ __device__ __forceinline__ v3 unit(v3 a) {
     const float lo = fminf(fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
     const float hi = fmaxf(fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
     const bool plain = lo >= 0x1p-40f && hi <= 0x1p40f;
-    if (__ballot(!plain) == 0ull) {
+    if (ballot64(!plain) == 0ull) {
         const float s = sqrt_plain(a.x * a.x + a.y * a.y + a.z * a.z);          // argument in [2^-80, 2^82)
         const float r = rcp_refined(s);
         return mk(div_plain(a.x, s, r), div_plain(a.y, s, r), div_plain(a.z, s, r));
@@ -208,7 +213,85 @@ __device__ __forceinline__ void random_in_unit_disk(Rng &r, float &px, float &py
 // its LCG step multiplies by 1 and adds 0 (the state stays), its z is fma(n, 0, 0) = +0, and (x*x + y*y) + 0 has the bits of x*x + y*y.
 // Every lane consumes exactly the draws the reference's loops consume, in their order.  `ball`: this lane wants a point of the unit
 // ball (else of the unit disk); only lanes with `need` enter.
-__device__ __forceinline__ void sample_ball_or_disk(Rng &r, bool need, bool ball, float &x, float &y, float &z, Cen *cn = nullptr) {
+#ifdef RTW_COOP_SAMPLER
+// EXPERIMENT (measured and rejected, profiles/r03_ab_coop.log): the wave-cooperative form of the loop.  Once at most eight
+// lanes are still without an accepted candidate, ONE wave-uniform round tests the next eight candidates of each of them in parallel: the wave is
+// eight blocks of eight lanes, the k-th pending lane ("owner") hands its stream to block k (ds_permute to the block's first lane, ds_swizzle
+// over the block), lane c of the block jumps the LCG ahead by c candidates (s' = A^j s + (1 + A + .. + A^(j-1)) inc, constants from a table),
+// draws and tests candidate c exactly as the plain loop would have, and the owner takes the FIRST accepted one of its block (a byte of the accept
+// ballot) with the state after it (ds_bpermute) -- the same draws, the same decisions, the same bits as the sequential loop.
+struct JumpTable { uint32_t a[16], c[16]; };
+__host__ __device__ constexpr JumpTable make_jump_table() {
+    JumpTable t{};
+    for (int e = 0; e < 16; e++) {                       // entries 0..7: candidate c of a DISK stream (2 draws each); 8..15: of a BALL stream (3 draws each)
+        const int j = (e < 8 ? 2 : 3) * (e & 7);
+        uint32_t a = 1u, c = 0u;
+        for (int k = 0; k < j; k++) { c = c * 747796405U + 1u; a = a * 747796405U; }     // s -> A s + inc, j times: (a, c) o (A, 1)
+        t.a[e] = a; t.c[e] = c;
+    }
+    return t;
+}
+__device__ __constant__ JumpTable RTW_JUMP = make_jump_table();
+
+__device__ __forceinline__ void coop_round(Rng &r, bool &pend, bool ball, float &x, float &y, float &z, float &len2, unsigned long long P, uint32_t lane, Cen *cn) {
+    RTW_CEN(cn, CEN_COOP);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(P >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)P, 0u));
+    // owners push (state, inc with the ball flag in its always-set low bit) to the first lane of their block; every other lane pushes to a lane
+    // that is nobody's first lane (its own block's last), so that no push can collide with an owner's
+    const int dst = (int)(pend ? rank << 5 : (lane << 2) | 28u);
+    const int t1 = __builtin_amdgcn_ds_permute(dst, (int)r.state);
+    const int t2 = __builtin_amdgcn_ds_permute(dst, (int)((r.inc & ~1u) | (ball ? 1u : 0u)));
+    const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_swizzle(t1, 0x18), b2 = (uint32_t)__builtin_amdgcn_ds_swizzle(t2, 0x18);   // lane & 0x18 of each half: the block's first lane
+    const bool bball = (b2 & 1u) != 0u;
+    const uint32_t binc = b2 | 1u, c = lane & 7u, e = c + (bball ? 8u : 0u);
+    uint32_t st = RTW_JUMP.a[e] * b1 + RTW_JUMP.c[e] * binc;                     // the owner's stream, c candidates ahead
+    float cx, cy, cz;
+    { uint32_t old = st; st = old * 747796405U + binc; cx = __builtin_fmaf((float)(old >> 8), 1.0f / 8388608.0f, -1.0f); }
+    { uint32_t old = st; st = old * 747796405U + binc; cy = __builtin_fmaf((float)(old >> 8), 1.0f / 8388608.0f, -1.0f); }
+    { const uint32_t old = st; st = bball ? old * 747796405U + binc : old; cz = bball ? __builtin_fmaf((float)(old >> 8), 1.0f / 8388608.0f, -1.0f) : 0.0f; }
+    const float l2 = cx * cx + cy * cy + cz * cz;
+    const unsigned long long M = ballot64(l2 <= 1.0f);
+    // the owner's block is byte `rank` of the accept mask; its lowest set bit is the first accepted candidate
+    const uint32_t mine = (uint32_t)(M >> (rank * 8u)) & 0xFFu;
+    const uint32_t cstar = mine ? (uint32_t)__builtin_ctz(mine) : 8u;
+    const int src = (int)((rank * 8u + (cstar < 8u ? cstar : 7u)) << 2);
+    const float nx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(cx)));
+    const float ny = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(cy)));
+    const float nl = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(l2)));
+    const float nz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(cz)));
+    const uint32_t ns = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)st);
+    if (pend) {
+        r.state = ns;                                   // after the accepted candidate, or after all eight
+        if (cstar < 8u) { x = nx; y = ny; z = nz; len2 = nl; pend = false; }
+    }
+}
+#ifndef RTW_COOP_MAX
+#define RTW_COOP_MAX 8
+#endif
+__device__ __forceinline__ void sample_ball_or_disk(Rng &r, bool need, bool ball, float &x, float &y, float &z, float &len2, Cen *cn = nullptr) {
+    bool pend = need;
+    const uint32_t am = ball ? 747796405U : 1U, ai = ball ? r.inc : 0U;
+    const float kz = ball ? (1.0f / 8388608.0f) : 0.0f, oz = ball ? -1.0f : 0.0f;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    for (;;) {
+        if (pend) {
+            RTW_CEN(cn, CEN_UV_TRIP);
+            x = rng_sym(r);
+            y = rng_sym(r);
+            const uint32_t old = r.state;
+            r.state = old * am + ai;
+            z = __builtin_fmaf((float)(old >> 8), kz, oz);
+            const float l2 = x * x + y * y + z * z;
+            len2 = l2;
+            if (l2 <= 1.0f) pend = false;
+        }
+        const unsigned long long P = ballot64(pend);
+        if (P == 0ull) break;
+        if ((uint32_t)__popcll(P) <= (uint32_t)RTW_COOP_MAX) coop_round(r, pend, ball, x, y, z, len2, P, lane, cn);
+    }
+}
+#else
+__device__ __forceinline__ void sample_ball_or_disk(Rng &r, bool need, bool ball, float &x, float &y, float &z, float &len2, Cen *cn = nullptr) {
     if (need) {
         const uint32_t am = ball ? 747796405U : 1U, ai = ball ? r.inc : 0U;
         const float kz = ball ? (1.0f / 8388608.0f) : 0.0f, oz = ball ? -1.0f : 0.0f;
@@ -223,6 +306,7 @@ __device__ __forceinline__ void sample_ball_or_disk(Rng &r, bool need, bool ball
             r.state = old * am + ai;
             z = __builtin_fmaf((float)(old >> 8), kz, oz);
             const float l2 = x * x + y * y + z * z;
+            len2 = l2;                               // |p|^2 of the accepted point: unit_of_ball_point() divides by its root
             if (l2 <= 1.0f) break;
 #ifdef RTW_EXPERIMENT_CAP_TRIPS      /* WRONG IMAGES: an upper bound on what any scheme that shortens the loop's tail can gain (profiles/r03_ab_coop_bound.log) */
             if (++trip >= RTW_EXPERIMENT_CAP_TRIPS) { const float s = 0.5f * __builtin_amdgcn_rsqf(l2); x *= s; y *= s; z *= s; break; }
@@ -230,6 +314,7 @@ __device__ __forceinline__ void sample_ball_or_disk(Rng &r, bool need, bool ball
         }
     }
 }
+#endif
 
 // ---- device scene ------------------------------------------------------------------------------
 // Hot, wave-uniform stream (scalar loads):  geom[i] = {cx, cy, cz, r*r},  vel[i] = {vx, vy, vz, 0}.
@@ -456,9 +541,29 @@ __device__ __forceinline__ bool on_hit_first(const MatP m, v3 normal, v3 dir, v3
     next = refl;
     return false;
 }
-// Second half: `p` is the accepted point of the unit ball (sample_ball_or_disk), `refl` the mirror direction of the first half.
-__device__ __forceinline__ v3 on_hit_second(float metallicness, v3 normal, v3 refl, bool front, v3 p) {
-    const v3 target = normal + unit(p);               // random_unit_vec = unit(accepted point) (vec3.rs:238)
+// unit(p) for an accepted point of the rejection sampler, whose |p|^2 = `l2` the sampler has just computed (the same expression, x*x + y*y + z*z).
+// The components are multiples of 2^-23 in [-1, 1): "every component in [2^-40, 2^40]" (unit()'s condition for the plain sequences) is "no component
+// is zero" here, and l2 is in [2^-46, 1].
+__device__ __forceinline__ v3 unit_of_ball_point(v3 p, float l2) {
+    const float lo = fminf(fminf(__builtin_fabsf(p.x), __builtin_fabsf(p.y)), __builtin_fabsf(p.z));
+    if (ballot64(!(lo > 0.0f)) == 0ull) {
+        const float s = sqrt_plain(l2);
+        const float r = rcp_refined(s);
+        return mk(div_plain(p.x, s, r), div_plain(p.y, s, r), div_plain(p.z, s, r));
+    }
+    return p / __builtin_sqrtf(l2);
+}
+// Second half: `p` is the accepted point of the unit ball (sample_ball_or_disk) and `l2` its squared length, `refl` the mirror direction of the first half.
+__device__ __forceinline__ v3 on_hit_second(float metallicness, v3 normal, v3 refl, bool front, v3 p, float l2) {
+    // random_unit_vec = unit(accepted point) (vec3.rs:238).  Handing the sampler's |p|^2 to the normalisation saves 7 VALU per SHADE step and costs more
+    // than that: the value is one more live register across the loop, and at 72 VGPRs the allocator then spills the traversal's tau -- a scratch
+    // load in every LEAF step (C4 -0.9 %, bench frame +-0; profiles/r03_ab_l2pass.log).  Off.
+#ifdef RTW_UNIT_FROM_L2
+    const v3 target = normal + unit_of_ball_point(p, l2);
+#else
+    (void)l2;
+    const v3 target = normal + unit(p);
+#endif
     const v3 sc = close_to_zero(target) ? normal : target;
     v3 next = refl * metallicness + sc * (1.0f - metallicness);
     if (close_to_zero(next)) next = front ? normal : normal * -1.0f;

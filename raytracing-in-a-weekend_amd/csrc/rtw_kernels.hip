@@ -106,7 +106,7 @@ __device__ __forceinline__ SubQ subq_layout(const KArgs &A, uint32_t sub) {
 }
 
 __device__ __forceinline__ bool fetch_pixel(const KArgs &A, bool need, Pixel &px, bool &exhausted, Reserve &rs) {
-    const unsigned long long m = __ballot(need);
+    const unsigned long long m = ballot64(need);
     if (m == 0ull) return false;
     if (rs.next == rs.end) {                                      // wave-uniform: refill the reserve
         if (rs.end == rs.limit) {
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(RTW_BLOCK) void resolve_kernel(const KArgs A) {
             if (col.x != col.x || col.y != col.y || col.z != col.z) nan = 1;
         }
     }
-    const unsigned long long m = __ballot(nan != 0);
+    const unsigned long long m = ballot64(nan != 0);
     if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&A.stats[4], (unsigned long long)__popcll(m));
 }
 
@@ -479,7 +479,7 @@ __device__ __forceinline__ void closest_brute(const DevScene &sc, v3 o, v3 d, fl
     cf4_ptr vel = (cf4_ptr)(uintptr_t)sc.vel;
     const float a = dot(d, d);
     const float ra = rcp_refined(a);
-    const bool a_plain = __ballot(!in_range(a, 0x1p-20f, 0x1p20f)) == 0ull;      // see sphere_root()
+    const bool a_plain = ballot64(!in_range(a, 0x1p-20f, 0x1p20f)) == 0ull;      // see sphere_root()
     best = -1; best_t = 0.0f;
     const uint32_t n = sc.n;
     auto test = [&](f4 g, f4 vv, uint32_t s) {
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_GEOM_BRUTE_WAVES : 1) void re
 
     for (;;) {
         if (fetch_pixel(A, !have && !dead, px, dead, rs)) { have = true; newpath = true; }
-        if (__ballot(!dead) == 0ull) break;
+        if (ballot64(!dead) == 0ull) break;
         if (++trips > RTW_MAX_TRIPS) { aborted = true; break; }       // safety valve, as in render_bvh
         if (have && newpath) { newpath = false; start_path<SPEC>(A, px, pt); n_rays++; }
         if (have) {
@@ -635,7 +635,7 @@ template <class S> __device__ __forceinline__ bool in_shade(int node) { return n
 // Lanes of the wave for which `c` holds, as a 32-bit SGPR value.  The empty asm hides the popcount's origin from the
 // optimiser, which otherwise carries it as 64 bits and compares it with VALU v_cmp_*_u64 on scalar operands.
 __device__ __forceinline__ uint32_t lanes_in(bool c) {
-    uint32_t n = (uint32_t)__popcll(__ballot(c));
+    uint32_t n = (uint32_t)__popcll(ballot64(c));
     asm volatile("" : "+s"(n));
     return n;
 }
@@ -666,6 +666,12 @@ __device__ __forceinline__ BvhBegin load_bvh_begin() {
     return b;
 }
 
+// The stack pointer is an ABSOLUTE LDS byte address (the dynamic-LDS base is already folded in when a query begins), so an
+// access is the ds instruction alone, no per-access address add.
+template <class T> __device__ __forceinline__ T lds_get(uint32_t addr) { return *(const __attribute__((address_space(3))) T *)(uintptr_t)addr; }
+template <class T> __device__ __forceinline__ void lds_put(uint32_t addr, T v) { *(__attribute__((address_space(3))) T *)(uintptr_t)addr = v; }
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
+
 template <bool MOVING, class S>
 __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav &tr, uint32_t sp0, bool a_plain_wave, bool &a_odd, Cen *cn = nullptr) {
     RTW_CEN(cn, CEN_TRAV_BEGIN);
@@ -674,7 +680,7 @@ __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav 
     tr.a = dot(d, d);
     tr.ra = rcp_refined(tr.a);
     a_odd = !in_range(tr.a, 0x1p-20f, 0x1p20f);           // (per lane; the caller folds it into the wave's sticky flag where the wave is whole)
-    const bool a_plain = a_plain_wave && __ballot(a_odd) == 0ull;
+    const bool a_plain = a_plain_wave && ballot64(a_odd) == 0ull;
     tr.best = -1; tr.best_t = A.maxt; tr.sp = sp0;           // the lane's level-0 slot (the sentinel)
     {   // big spheres: uniform loop, scalar loads
         cf4_ptr bg = (cf4_ptr)(uintptr_t)bv.big_geom;
@@ -724,11 +730,6 @@ __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav 
     tr.hi_lim = tr.best_t + tr.tau_t;
 }
 
-// The stack pointer is an ABSOLUTE LDS byte address (the dynamic-LDS base is already folded in when a query begins), so an
-// access is the ds instruction alone, no per-access address add.
-template <class T> __device__ __forceinline__ T lds_get(uint32_t addr) { return *(const __attribute__((address_space(3))) T *)(uintptr_t)addr; }
-template <class T> __device__ __forceinline__ void lds_put(uint32_t addr, T v) { *(__attribute__((address_space(3))) T *)(uintptr_t)addr = v; }
-__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
 
 // After a leaf test: take the next entry off the stack (the sentinel of level 0 ends the query).
 template <class S>
@@ -849,10 +850,13 @@ __device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr) {
 #define RTW_BVH_WAVES_SPEC 7   /* the specialised builds (SPEC != 0) are compiled for 7 waves/SIMD = 72 VGPRs (two dwords of scratch in the static builds, ten in the MOVING
                                   ones); whether the seventh workgroup per CU is used depends on the LDS the tree needs and on the size of the launch (rtw_shim.hip) */
 #endif
+#ifndef RTW_BVH_WAVES_SPEC2
+#define RTW_BVH_WAVES_SPEC2 RTW_BVH_WAVES_SPEC   /* the build that keeps the image-texture lookup (C5) */
+#endif
 // NODES: 0 = f32 nodes in global memory, 32-bit stack; 1 = f16 nodes in LDS, 16-bit stack; 2 = as 1, and the spheres' {centre, r^2} in LDS
 // too (a build of its own: as a run-time choice the leaf test went through a flat load and a select of two addresses, 7 VALU).
 template <bool MOVING, int NODES, int SPEC, bool GEOM>
-__global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ? RTW_BVH_WAVES_SPEC : RTW_BVH_WAVES)) void render_bvh(const KArgs A) {
+__global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC == 2 ? RTW_BVH_WAVES_SPEC2 : (SPEC != 0 ? RTW_BVH_WAVES_SPEC : RTW_BVH_WAVES))) void render_bvh(const KArgs A) {
     constexpr bool LDSN = NODES != 0, geom_in_lds = NODES == 2;
     // LDS is all dynamic, sized by the host for THIS tree (rtw_shim.hip, render_enqueue_impl): -- LDS-node variants -- the f16 nodes at
     // offset 0, then the per-lane traversal stack [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel,
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             // a. the closest-hit query this lane was waiting on is complete: scatter, or end the path
             bool need_unit = false, started = false, a_odd = false;
             const bool shading = in_shade<stack_t>(tr.node);
-            w_seg += (uint32_t)__popcll(__ballot(shading && (fl & F_INFLIGHT) != 0u));
+            w_seg += (uint32_t)__popcll(ballot64(shading && (fl & F_INFLIGHT) != 0u));
 #ifdef RTW_STAMP
             t_sub = t_begin;
 #endif
@@ -971,7 +975,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             // b. next work unit (every lane of the wave: the reserve stays wave-uniform; see the generic path below)
             bool exhausted = false;
             const bool got = fetch_pixel(A, need_unit, px, exhausted, rs);
-            if (__ballot(exhausted) != 0ull) t_lo = RTW_T_LO_DRAIN;
+            if (ballot64(exhausted) != 0ull) t_lo = RTW_T_LO_DRAIN;
             RTW_SUB_STAMP(1);
             if (shading) {
                 if (got) fl |= F_HAVE | F_NEWPATH;
@@ -982,9 +986,9 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             //    ... the hit, up to its random unit vector
             if (hit) shade_hit_first<MOVING, SPEC>(A, pt, ud, tr.best, tr.best_t, need_ball, nrm, metal, front, cn);
             // d. ONE rejection loop: points of the unit ball for the lanes that scatter, of the unit disk for the lanes that start a path
-            float sx, sy, sz;
-            sample_ball_or_disk(pt.rng, need_ball || need_disk, need_ball, sx, sy, sz, cn);
-            if (need_ball) pt.d = on_hit_second(metal, nrm, pt.d, front, mk(sx, sy, sz));
+            float sx, sy, sz, sl2;
+            sample_ball_or_disk(pt.rng, need_ball || need_disk, need_ball, sx, sy, sz, sl2, cn);
+            if (need_ball) pt.d = on_hit_second(metal, nrm, pt.d, front, mk(sx, sy, sz), sl2);     // (sl2: see RTW_UNIT_FROM_L2, rtw_device.h)
             if (need_disk) start_path_second(px, pt, sx, sy);
             RTW_SUB_STAMP(2);
             // e. start the next closest-hit query
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             // "few lanes traverse" rule alone -- after finding the queue empty a wave runs on for 0.38 ms on average and 1.2 ms at most
             // (profiles/r02_endtimes.log).  The threshold of that rule can differ while draining (RTW_T_LO_DRAIN; measured, not better).
             // (HERE, where every lane of the wave is active: t_lo steers the scheduler and must stay wave-uniform.)
-            if (__ballot(exhausted) != 0ull) t_lo = RTW_T_LO_DRAIN;
+            if (ballot64(exhausted) != 0ull) t_lo = RTW_T_LO_DRAIN;
             RTW_SUB_STAMP(1);
 #ifdef RTW_STAMP
             if (shading) {
@@ -1045,10 +1049,10 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC != 0 ?
             }
             RTW_SUB_STAMP(3);
             }
-            w_rays += (uint32_t)__popcll(__ballot(started));
+            w_rays += (uint32_t)__popcll(ballot64(started));
             // Wave-uniform and STICKY: lanes of this wave still test leaves of queries begun in earlier SHADE steps, so once any lane's d.d
             // has left [2^-20, 2^20] the wave stays on the generic sqrt / division (same bits, a few more instructions) for good.
-            if (__ballot(a_odd) != 0ull) a_plain = false;
+            if (ballot64(a_odd) != 0ull) a_plain = false;
 #ifndef RTW_STAMP
             nT = lanes_in(in_trav<stack_t>(tr.node)); burst = nT >= 33u;      // (as after a LEAF step)
 #endif
