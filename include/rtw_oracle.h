@@ -67,6 +67,10 @@ void  rtw_oracle_ln_bulk(const float *x, float *out, size_t n);
  * as usize (emission != 0: floor() first, as :95-96 write it), clamped to the last texel where the reference would panic. */
 uint32_t rtw_oracle_rust2_texel_index(float u, float v, uint32_t width, uint32_t height, int emission);
 
+/* TEST ONLY: the spherical UV of sphere.rs:132-133 for n unit normals, through libm (plain == 0: what the oracle renders with) or through a
+ * restatement of the device's lean atan2 / acos sequences (plain != 0).  out: [n][4] = atan2, acos, u, v. */
+void  rtw_oracle_sphere_uv(const float *normals, size_t n, int plain, float *out);
+
 /* Vec3::rotated (Rust/src/vec3.rs:161-181), for the reference's rotation_tests known answers (vec3.rs:363-404). */
 void  rtw_oracle_rotated(const float v[3], const float rot[3], float out[3]);
 

@@ -195,6 +195,50 @@ static v3 sphere_albedo(const RtwScene *sc, const RtwSphere *s, v3 normal) {
     return v3_mul(tex, v3_ld(s->col_mod));        /* sphere.rs:145 */
 }
 
+/* TEST ONLY: the device's lean atan2 / acos for the spherical UV (csrc/rtw_device.h atan2_plain / acos_plain), restated operation for operation --
+ * `/` and sqrtf are correctly rounded here, as div_plain / sqrt_plain are on the device for the arguments they are used with -- so that their
+ * accuracy and their effect on the texel choice can be measured on the CPU (tests/test_round3_cpu.py).  The oracle's own renders use libm
+ * (sphere_albedo below), like the reference (Rust's f32::atan2 / f32::acos). */
+static float atan2_plain(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float k = fmaxf(ax, ay) < 0x1p-60f ? 0x1p80f : 1.0f;
+    const float mx = fmaxf(ax, ay) * k, mn = fminf(ax, ay) * k;
+    const float t = mx == 0.0f ? 0.0f : mn / mx;
+    const float s = t * t;
+    float p = 0.002974563976749778f;
+    p = fmaf(p, s, -0.016581078991293907f); p = fmaf(p, s, 0.043553370982408524f); p = fmaf(p, s, -0.07580564171075821f);
+    p = fmaf(p, s, 0.10678933560848236f);   p = fmaf(p, s, -0.14214207231998444f); p = fmaf(p, s, 0.19994136691093445f);
+    p = fmaf(p, s, -0.3333316743373871f);
+    float a = fmaf(t * s, p, t);
+    a = ay > ax ? 1.57079632679489661923f - a : a;
+    a = signbit(x) ? 3.14159265358979323846f - a : a;
+    a = (x != x || y != y) ? NAN : a;
+    return copysignf(a, y);
+}
+static float acos_plain(float x) {
+    const float ax = fabsf(x);
+    const int small = ax <= 0.5f;
+    const float s = small ? x * x : (1.0f - ax) * 0.5f;
+    const float q = small ? x : sqrtf(s);
+    float p = 0.04221854731440544f;
+    p = fmaf(p, s, 0.02414761111140251f); p = fmaf(p, s, 0.04547709599137306f); p = fmaf(p, s, 0.07495241612195969f);
+    p = fmaf(p, s, 0.16666753590106964f);
+    const float r = fmaf(q * s, p, q);
+    const float two = r + r;
+    return small ? 1.57079632679489661923f - r : (x < 0.0f ? 3.14159265358979323846f - two : two);
+}
+/* (u, v) of sphere.rs:132-133 for n normals; plain != 0: through the device's sequences, else through libm.  out: [n][4] = atan2, acos, u, v */
+void rtw_oracle_sphere_uv(const float *normals, size_t n, int plain, float *out) {
+    const float PI = 3.14159265358979323846f, FRAC_1_PI = 0.318309886183790671538f;
+    for (size_t i = 0; i < n; i++) {
+        const float y = -normals[3 * i + 2], x = normals[3 * i], c = -normals[3 * i + 1];
+        const float at = plain ? atan2_plain(y, x) : atan2f(y, x), ac = plain ? acos_plain(c) : acosf(c);
+        out[4 * i] = at; out[4 * i + 1] = ac;
+        out[4 * i + 2] = (at + PI) * FRAC_1_PI * 0.5f;
+        out[4 * i + 3] = 1.0f - (FRAC_1_PI * ac);
+    }
+}
+
 /* Rust2's ImageTexture::color_at (Rust2/src/objects/texture.rs:94-105) as written: the sample of an image of `width` x `height` texels at
  * (u, v) is img[x * width + y] with x = (u * width) as usize, y = (v * height) as usize -- scaled by the size (not size - 1 as in Rust/) and
  * indexed TRANSPOSED (x * width + y, not y * width + x: most likely a bug, and part of the contract); the emission image

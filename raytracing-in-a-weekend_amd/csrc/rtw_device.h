@@ -329,7 +329,7 @@ struct DevMat {
     float emitted[3];
     float r0_front;       // ((1 - 1/ir) / (1 + 1/ir))^2     } (materials.rs:99-100,113), done once on the host: the same
     float r0_back;        // ((1 - ir) / (1 + ir))^2         } single IEEE f32 operations, hoisted like radius * radius
-    uint32_t pad[3];
+    uint32_t tex_row, tex_col, tex_offset;   // tex >= 0: RtwTexture.row / col / texel_offset of that image, copied by the host (one dependent load less per textured hit)
 };
 static_assert(sizeof(DevMat) == 64, "DevMat is four f4 rows");
 
@@ -402,16 +402,61 @@ __device__ __forceinline__ uint32_t tex_index(float f, uint32_t last) {
     return (uint32_t)f;
 }
 
+// ---- the two libm calls of the spherical UV (sphere.rs:132-133: f32::atan2, f32::acos) ---------------------------------------------------
+// Rust's f32::atan2 / acos are the platform libm's, accurate to about an ulp; which ulp decides nothing but on which side of a texel edge a
+// hit within ~1e-7 of it falls ("a texel edge can move by an ulp").  ocml's atan2f + acosf cost ~130 VALU instructions of every
+// SHADE step of a textured scene (C5: +9 % of the frame, profiles/r02_c5_parts.log), most of it for arguments a unit normal cannot have.
+// The two below are the same classic reductions with minimax polynomials (fitted for this file; max error against f64 over 4 M random unit
+// normals, evaluated in f32 with one rounding per operation: atan2 2.03 ulp, acos 1.25 ulp; texel choice against a correctly rounded libm:
+// identical for textures up to 4 x 4, 2 texels per million hits for a 128-texel-wide image -- tests/test_round3_cpu.py re-measures both from
+// the oracle's copy of the same code).  There is NO second path through ocml behind a range check (tried: with both inlined the C5 kernel went
+// from 52 to 80 bytes of scratch and from 93.3 to 101.6 ms, profiles/r03_ab_c5_uv.log): the two functions are total -- atan2(+-0, +-0) and NaN
+// arguments give libm's answers, tiny arguments are rescaled, acos of |x| > 1 is NaN.
+//   atan2(y, x):  t = min / max (correctly rounded), atan t = t + t s P(s), s = t^2, then the octant fix-ups
+__device__ __forceinline__ float atan2_plain(float y, float x) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float k = fmaxf(ax, ay) < 0x1p-60f ? 0x1p80f : 1.0f;                      // (a direction's arctangent does not depend on its length)
+    const float mx = fmaxf(ax, ay) * k, mn = fminf(ax, ay) * k;
+    const float t = mx == 0.0f ? 0.0f : div_plain(mn, mx, rcp_refined(mx));           // atan2(+-0, +-0) = +-0 or +-pi: t = 0
+    const float s = t * t;
+    float p = 0.002974563976749778f;
+    p = __builtin_fmaf(p, s, -0.016581078991293907f); p = __builtin_fmaf(p, s, 0.043553370982408524f); p = __builtin_fmaf(p, s, -0.07580564171075821f);
+    p = __builtin_fmaf(p, s, 0.10678933560848236f);   p = __builtin_fmaf(p, s, -0.14214207231998444f); p = __builtin_fmaf(p, s, 0.19994136691093445f);
+    p = __builtin_fmaf(p, s, -0.3333316743373871f);
+    float a = __builtin_fmaf(t * s, p, t);
+    a = ay > ax ? 1.57079632679489661923f - a : a;
+    a = __float_as_int(x) < 0 ? 3.14159265358979323846f - a : a;                     // the SIGN of x, so that atan2(y, -0) is libm's
+    a = (x != x || y != y) ? __builtin_nanf("") : a;
+    return __builtin_copysignf(a, y);
+}
+//   acos(x), |x| <= 1:  |x| <= 1/2: pi/2 - asin x;  else 2 asin sqrt((1 - |x|) / 2), reflected for x < 0;  asin q = q + q s R(s)
+__device__ __forceinline__ float acos_plain(float x) {
+    const float ax = __builtin_fabsf(x);
+    const bool small = ax <= 0.5f;
+    const float s = small ? x * x : (1.0f - ax) * 0.5f;
+    const float q = small ? x : sqrt_plain(s);
+    float p = 0.04221854731440544f;
+    p = __builtin_fmaf(p, s, 0.02414761111140251f); p = __builtin_fmaf(p, s, 0.04547709599137306f); p = __builtin_fmaf(p, s, 0.07495241612195969f);
+    p = __builtin_fmaf(p, s, 0.16666753590106964f);
+    const float r = __builtin_fmaf(q * s, p, q);
+    const float two = r + r;
+    return small ? 1.57079632679489661923f - r : (x < 0.0f ? 3.14159265358979323846f - two : two);
+}
+// (u, v) of a sphere's outward normal (sphere.rs:132-133)
+__device__ __forceinline__ void sphere_uv(v3 normal, float &u, float &v) {
+    const float PI = 3.14159265358979323846f, FRAC_1_PI = 0.318309886183790671538f;
+    u = (atan2_plain(-normal.z, normal.x) + PI) * FRAC_1_PI * 0.5f;
+    v = 1.0f - (FRAC_1_PI * acos_plain(-normal.y));
+}
+
 // sphere.rs:129-146 + texture.rs:259-267
 __device__ __forceinline__ v3 sphere_albedo(const DevScene &sc, const DevMat &m, v3 normal) {
     if (m.tex < 0) return ld3(m.cm);
-    const RtwTexture t = sc.tex[m.tex];
-    const float PI = 3.14159265358979323846f, FRAC_1_PI = 0.318309886183790671538f;
-    float u = (atan2f(-normal.z, normal.x) + PI) * FRAC_1_PI * 0.5f;
-    float v = 1.0f - (FRAC_1_PI * acosf(-normal.y));
-    uint32_t tx = tex_index(floorf(u * (float)(t.row - 1)), t.row - 1);
-    uint32_t ty = tex_index(floorf(v * (float)(t.col - 1)), t.col - 1);
-    const float *px = sc.texels + 3 * (size_t)(t.texel_offset + ty * t.row + tx);
+    float u, v;
+    sphere_uv(normal, u, v);
+    uint32_t tx = tex_index(floorf(u * (float)(m.tex_row - 1)), m.tex_row - 1);
+    uint32_t ty = tex_index(floorf(v * (float)(m.tex_col - 1)), m.tex_col - 1);
+    const float *px = sc.texels + 3 * (size_t)(m.tex_offset + ty * m.tex_row + tx);
     return (ld3(px) * 1.0f) * ld3(m.cm);
 }
 
@@ -427,9 +472,8 @@ __device__ __forceinline__ uint32_t rust2_texel_index(float u, float v, uint32_t
 }
 __device__ __forceinline__ void rust2_sphere_color(const DevScene &sc, const DevMat &m, v3 normal, v3 &multiplied, v3 &emmited) {
     const RtwTexture t = sc.tex[m.tex];
-    const float PI = 3.14159265358979323846f, FRAC_1_PI = 0.318309886183790671538f;
-    const float u = (atan2f(-normal.z, normal.x) + PI) * FRAC_1_PI * 0.5f;
-    const float v = 1.0f - (FRAC_1_PI * acosf(-normal.y));
+    float u, v;
+    sphere_uv(normal, u, v);
     multiplied = ld3(sc.texels + 3 * (size_t)(t.texel_offset + rust2_texel_index(u, v, t.row, t.col, false))) * ld3(m.cm);   // (cm = col_mod: 1 in a Rust2 scene)
     if (t.emit_tex != 0u) {
         const RtwTexture e = sc.tex[t.emit_tex - 1u];

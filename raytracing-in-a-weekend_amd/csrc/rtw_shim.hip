@@ -98,7 +98,7 @@ struct OutSpec {
 };
 
 // The device records of a sphere list (sphere.rs:13-20 + materials.rs:15-20)
-static void prepare_spheres(const RtwSphere *sp, uint32_t n, std::vector<f4> &geom, std::vector<f4> &vel, std::vector<DevMat> &mat, bool &moving) {
+static void prepare_spheres(const RtwSphere *sp, uint32_t n, const RtwTexture *tex, std::vector<f4> &geom, std::vector<f4> &vel, std::vector<DevMat> &mat, bool &moving) {
     geom.resize(n); vel.resize(n); mat.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const RtwSphere &s = sp[i];
@@ -113,6 +113,9 @@ static void prepare_spheres(const RtwSphere *sp, uint32_t n, std::vector<f4> &ge
             m.emitted[k] = s.emitted[k];
         }
         m.metallicness = s.metallicness; m.opacity = s.opacity; m.ir = s.ir; m.tex = s.tex;
+        // the image's shape and place ride along in the material record: the texel fetch then depends on ONE load (this record), not on a second one
+        // of the RtwTexture behind it (a SHADE step of a textured scene was three dependent global loads deep: material -> texture -> texel)
+        if (s.tex >= 0 && tex) { m.tex_row = tex[s.tex].row; m.tex_col = tex[s.tex].col; m.tex_offset = tex[s.tex].texel_offset; }
         m.inv_ir = host_div(1.0f, s.ir);                         // materials.rs:113  1.0 / self.ir
         m.r0_front = schlick_r0(m.inv_ir); m.r0_back = schlick_r0(s.ir);   // materials.rs:99-100 for either ratio
     }
@@ -279,7 +282,7 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     std::vector<f4> geom, vel;
     std::vector<DevMat> mat;
     bool moving = false;
-    prepare_spheres(s->spheres, s->n_spheres, geom, vel, mat, moving);
+    prepare_spheres(s->spheres, s->n_spheres, s->textures, geom, vel, mat, moving);
     std::vector<RtwTexture> tex(s->textures, s->textures + s->n_textures);
     std::vector<float> texels(s->texels, s->texels + 3 * (size_t)s->n_texels);
 
@@ -296,7 +299,7 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
         bool imoving = false;
         prepare_quads(s->quads, s->n_quads, quads);
         prepare_quads(s->inst_quads, s->n_inst_quads, iquads);
-        prepare_spheres(s->inst_spheres, s->n_inst_spheres, igeom, ivel, imat, imoving);
+        prepare_spheres(s->inst_spheres, s->n_inst_spheres, s->textures, igeom, ivel, imat, imoving);
         for (uint32_t i = 0; i < s->n_instances; i++) {
             const RtwInstance &in = s->instances[i];
             DevInstance &d = inst[i];

@@ -48,6 +48,8 @@ def lib():
         L.rtw_oracle_rng_next.restype = C.c_float
         L.rtw_oracle_rust2_texel_index.argtypes = [C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_int]
         L.rtw_oracle_rust2_texel_index.restype = C.c_uint32
+        L.rtw_oracle_sphere_uv.argtypes = [fp, C.c_size_t, C.c_int, fp]
+        L.rtw_oracle_sphere_uv.restype = None
         L.rtw_oracle_rotated.argtypes = [fp, fp, fp]
         L.rtw_oracle_rotated.restype = None
         _lib = L

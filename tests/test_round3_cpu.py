@@ -156,3 +156,45 @@ def test_truncated_lcg_and_permuted_stream_render_the_same_image():
     assert ta[0] == tb[0] == 400 * 225 * 10                                # every path has a first query
     zt = (ta[1:] - tb[1:]) / np.sqrt(ta[1:] + tb[1:])
     assert np.abs(zt).max() < 4.0, zt
+
+
+# ---- the device's lean atan2 / acos for the spherical UV (csrc/rtw_device.h atan2_plain / acos_plain) --------------------------------------
+def test_lean_atan2_acos_accuracy_and_texel_choice():
+    """The device computes the UV of a textured sphere (sphere.rs:132-133) with its own reductions instead of ocml's atan2f / acosf (~130 VALU
+    of every SHADE step of C5).  Measured here on the oracle's operation-for-operation copy: against f64 over 2 M random unit normals (and the
+    axes), atan2 <= 2.5 ulp, acos <= 1.5 ulp -- libm grade --, and the texel the reference's rule floor(u * (row - 1)) picks agrees with the
+    libm path for all but a few hits per million even on a 1024-texel-wide image."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=(2_000_000, 3))
+    v /= np.linalg.norm(v, axis=1)[:, None]
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 0, 1], [0, 0, -1], [0.6, 0.8, 0], [0, 0.6, -0.8], [1e-20, 1, 1e-20], [-1e-3, -1, 1e-9],
+                     [0.5, 0.5, 0.70710678], [-0.5, -0.5, 0.70710678]], dtype=np.float64)
+    n = np.ascontiguousarray(np.concatenate([v, axes]).astype(np.float32))
+    fp = C.POINTER(C.c_float)
+    out = {}
+    for plain in (0, 1):
+        o = np.empty((len(n), 4), np.float32)
+        O.lib().rtw_oracle_sphere_uv(n.ctypes.data_as(fp), len(n), plain, o.ctypes.data_as(fp))
+        out[plain] = o
+    n64 = n.astype(np.float64)
+    at = np.arctan2(-n64[:, 2], n64[:, 0]); ac = np.arccos(np.clip(-n64[:, 1], -1, 1))
+
+    def ulps(got, ref):
+        return np.abs(got.astype(np.float64) - ref) / np.maximum(np.spacing(np.abs(ref.astype(np.float32))).astype(np.float64), 1e-45)
+    e_at, e_ac = ulps(out[1][:, 0], at), ulps(out[1][:, 1], ac)
+    assert e_at.max() <= 2.5 and e_ac.max() <= 1.5, (e_at.max(), e_ac.max())
+    assert e_at.mean() < 0.5 and e_ac.mean() < 0.5
+    # the special values: libm's answers for zeros of either sign, NaN in, NaN out; a direction of denormal length is still a direction
+    sp = np.float32([[0.0, 1.0, -0.0], [-0.0, 1.0, -0.0], [0.0, -1.0, 0.0], [-0.0, -1.0, 0.0], [np.nan, 0.0, 1.0], [1.0, 2.0, 0.0],
+                     [3e-42, 1.0, -4e-42], [-2e-39, 0.5, 1e-39]])
+    a, b = np.empty((len(sp), 4), np.float32), np.empty((len(sp), 4), np.float32)
+    O.lib().rtw_oracle_sphere_uv(np.ascontiguousarray(sp).ctypes.data_as(fp), len(sp), 0, a.ctypes.data_as(fp))
+    O.lib().rtw_oracle_sphere_uv(np.ascontiguousarray(sp).ctypes.data_as(fp), len(sp), 1, b.ctypes.data_as(fp))
+    ok = ~np.isnan(a[:, 0])
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.signbit(a[ok, 0]), np.signbit(b[ok, 0]))
+    np.testing.assert_allclose(b[~np.isnan(a)], a[~np.isnan(a)], rtol=3e-7, atol=1e-7)
+    for size in (2, 4, 128, 1024):
+        for col in (2, 3):
+            a = np.floor(out[0][:, col] * np.float32(size - 1)); b = np.floor(out[1][:, col] * np.float32(size - 1))
+            assert (a != b).mean() < (1e-6 if size <= 4 else 5e-5), (size, col, (a != b).mean())
