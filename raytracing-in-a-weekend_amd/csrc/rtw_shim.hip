@@ -742,7 +742,7 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
         }
 #endif
 #if defined(RTW_STAMP) || defined(RTW_ENDTIMES)     // diagnostic builds only (scripts/gpu_endtimes.py)
-        if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu   of shade: hit %llu, bank + next unit %llu, camera ray %llu, query begin %llu\n",
+        if (getenv("RTW_STAMP_DUMP")) std::fprintf(stderr, "rtw stamp: wave-ticks traverse %llu leaf %llu shade %llu   of shade (specialised builds): a. unit(d) + paths that end %llu, b. bank + next unit %llu, c-d. hit / path start + the rejection loop + second halves %llu, e. query begin %llu   (generic build: hit, bank + next unit, camera ray, query begin)\n",
                                                    h_stats[11], h_stats[12], h_stats[13], h_stats[16], h_stats[17], h_stats[18], h_stats[19]);
         if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15] && getenv("RTW_ENDTIMES_REF")) {
             std::fprintf(stderr, "rtw endtimes histogram (waves ending in each 1/32 of the reference lifetime, bins 21/32 .. 32/32+; bin 0 also holds everything earlier):");
