@@ -697,16 +697,32 @@ __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav 
     // the hardware approximations (v_sqrt_f32 / v_rcp_f32 / v_rsq_f32, <= 1 ulp) are used with the
     // 1e-4 relative safety factors below instead of the correctly-rounded sequences.
     const float ex = o.x - bv.cx, ey = o.y - bv.cy, ez = o.z - bv.cz;
+#ifdef RTW_BEGIN_L2_NORM
     const float M = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + bv.centre_radius;
+#else
+    // an UPPER bound of |o - C| is all that is needed: the 1-norm (two additions with |.| modifiers instead of three products, two sums and a root).
+    // It is at most sqrt(3) times the distance, which makes rho / tau -- 1e-6-sized paddings against spheres of radius 0.2 -- at most 3x / 1.7x as large
+    const float M = (__builtin_fabsf(ex) + __builtin_fabsf(ey) + __builtin_fabsf(ez)) * 1.0001f + bv.centre_radius;
+#endif
     const float q = (M * M + bv.r_max2) * RTW_KU;
     const float sq_q = __builtin_amdgcn_sqrtf(q) * 1.0001f;
     float rho = fminf(q * bv.inv_2rmin, sq_q);
     rho = rho * 1.0001f + 4.8e-7f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + bv.abs_max);   // + slab-arithmetic slop (8u * magnitudes)
     tr.tau_t = sq_q * 1.0002f * __builtin_amdgcn_rsqf(tr.a) + 1e-30f;
     float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+#ifdef RTW_BEGIN_GUARD_PER_LANE
     if (!(fabsf(d.x) >= 1e-20f)) ix = copysignf(1e20f, d.x);
     if (!(fabsf(d.y) >= 1e-20f)) iy = copysignf(1e20f, d.y);
     if (!(fabsf(d.z) >= 1e-20f)) iz = copysignf(1e20f, d.z);
+#else
+    // a component of the direction that is (nearly) zero or NaN gets a huge finite reciprocal of its sign: checked for the whole wave with one
+    // three-way minimum, so that the three compare / select pairs are only executed by waves that hold such a ray
+    if (ballot64(!(fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)) >= 1e-20f) || d.x != d.x || d.y != d.y || d.z != d.z) != 0ull) {
+        if (!(fabsf(d.x) >= 1e-20f)) ix = copysignf(1e20f, d.x);
+        if (!(fabsf(d.y) >= 1e-20f)) iy = copysignf(1e20f, d.y);
+        if (!(fabsf(d.z) >= 1e-20f)) iz = copysignf(1e20f, d.z);
+    }
+#endif
     tr.ix = ix; tr.iy = iy; tr.iz = iz;
     if (sizeof(S) == 2) {
         // LDS nodes: a ray along +axis enters a box through lo and leaves through hi, one along -axis the other way round, so
