@@ -685,9 +685,13 @@ __device__ __forceinline__ void trav_begin(const KArgs &A, const Path &pt, Trav 
     {   // big spheres: uniform loop, scalar loads
         cf4_ptr bg = (cf4_ptr)(uintptr_t)bv.big_geom;
         cf4_ptr bvel = (cf4_ptr)(uintptr_t)bv.big_vel;
+        // (the sphere's index in the scene list through the constant address space too: as a generic pointer the compiler fetched it with a
+        //  per-lane flat load of a wave-uniform address and waited for it -- a global-memory round trip in every SHADE step)
+        typedef const uint32_t __attribute__((address_space(4))) *cu32_ptr;
+        cu32_ptr bidx = (cu32_ptr)(uintptr_t)bv.big_index;
         for (uint32_t k = 0; k < bv.n_big; ++k) {
             f4 vv = MOVING ? bvel[k] : f4{ 0, 0, 0, 0 };
-            exact_sphere<MOVING>(bg[k], vv, bv.big_index[k], o, d, pt.tm, tr.a, tr.ra, a_plain, A.mint, A.maxt, tr.best, tr.best_t);
+            exact_sphere<MOVING>(bg[k], vv, bidx[k], o, d, pt.tm, tr.a, tr.ra, a_plain, A.mint, A.maxt, tr.best, tr.best_t);
         }
     }
     if (bv.root == (int)0x80000000) { tr.node = (int)Code<S>::END; return; }   // no tree: the query is complete
