@@ -267,9 +267,9 @@ __device__ __forceinline__ void shade_miss(const KArgs &A, Path &pt, v3 ud) {
     if (integ<SPEC>(A) == RTW_INTEGRATOR_BG_COLOR || integ<SPEC>(A) == RTW_INTEGRATOR_RUST2) miss = ld3(A.bg);
     else if (integ<SPEC>(A) == RTW_INTEGRATOR_FLAG) miss = mk(0.0f, 0.0f, 1.0f);
     else miss = sky_gradient(ud);
-    // SPEC builds (ray_color_gradient): nothing has been gathered before the path ends, pt.L is 0 -- written out as a literal so that L
-    // is not carried from step to step (and not exchanged by render_bvh2's SWITCH); 0 + x keeps the oracle's rounding and sign of zero
-    if (SPEC) pt.L = mk(0.0f, 0.0f, 0.0f) + miss * pt.thr;
+    // SPEC builds (ray_color_gradient): nothing has been gathered before the path ends, pt.L is 0 -- so L is not carried from step to step -- and
+    // the oracle's `0 + x` is x itself except for x = -0, which the resolve pass's own `0 + ..` (the pixel's sum starts at +0) turns into the same +0
+    if (SPEC) pt.L = miss * pt.thr;
     else pt.L = pt.L + miss * pt.thr;
 }
 
