@@ -684,7 +684,17 @@ __device__ __forceinline__ void quad_test(const DevScene &sc, const DevQuad *qua
     const v3 normal = mk(r3.x, r3.y, r3.z);
     const float denominator = dot(normal, d);
     if (__builtin_fabsf(denominator) <= 1e-8f) return;
-    const float t = (r0.w - dot(normal, o)) / denominator;
+    // (Measured and rejected, round 3: the same correctly rounded quotient through div_plain when every lane's operands are ordinary saves 6 of the
+    //  division's 12 instructions and costs a range check, a ballot and a second code path per quad test: presentation_image 183.5 instead of 170.3 ms,
+    //  images identical -- profiles/r03_ab_quad_div.log.  -DRTW_QUAD_PLAIN_DIV builds it.)
+    const float numerator = r0.w - dot(normal, o);
+    float t;
+#ifdef RTW_QUAD_PLAIN_DIV
+    const bool plain = in_range(denominator, 0x1p-40f, 0x1p40f) && (numerator == 0.0f || in_range(numerator, 0x1p-60f, 0x1p40f));
+    if (ballot64(!plain) == 0ull) t = div_plain(numerator, denominator, rcp_refined(denominator));
+    else
+#endif
+        t = numerator / denominator;
     if (t < mint || t > maxt) return;
     if (found && !(h.t > t)) return;                           // cannot replace the current hit (`min_hit > i` is strict): skip the interior test
     const f4 r1 = q[1], r2 = q[2], r4 = q[4];
