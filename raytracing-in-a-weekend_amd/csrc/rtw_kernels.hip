@@ -981,14 +981,21 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC == 2 ?
                     fl &= ~F_INFLIGHT;
                     RTW_CEN(cn, CEN_INFLIGHT);
                     ud = unit(pt.d);
-                    if (tr.best < 0) { RTW_CEN(cn, CEN_MISS); shade_miss<SPEC>(A, pt, ud); fl |= F_DONE; }
-                    else if ((fl >> F_K_SHIFT) + 1u >= A.depth) { RTW_CEN(cn, CEN_DEPTH_END); pt.L = mk(0, 0, 0); fl |= F_DONE; }   // depth exhausted: the innermost call returns black
+                    // (the radiance of a path that ends -- sky, or black at exhausted depth -- is formed in the bank block below, where it is
+                    //  stored: formed here it lived across the join, three registers that the MOVING builds spilled and reloaded in every step)
+                    if (tr.best < 0) { RTW_CEN(cn, CEN_MISS); fl |= F_DONE; }
+                    else if ((fl >> F_K_SHIFT) + 1u >= A.depth) { RTW_CEN(cn, CEN_DEPTH_END); fl |= F_DONE; }   // depth exhausted: the innermost call returns black
                     else { hit = true; fl += 1u << F_K_SHIFT; }         // (the bounce count of these builds: Path.k is not carried)
                 }
             }
             RTW_SUB_STAMP(0);
             if (shading) {
-                if (fl & F_DONE) { fl &= ~F_DONE; if (finish_path<SPEC>(A, px, pt, cn)) fl &= ~F_HAVE; else fl |= F_NEWPATH; }
+                if (fl & F_DONE) {
+                    fl &= ~F_DONE;
+                    // in these builds F_DONE is only ever set a few lines up, in this same step: tr.best still tells a miss from an exhausted depth
+                    if (tr.best < 0) shade_miss<SPEC>(A, pt, ud); else pt.L = mk(0, 0, 0);
+                    if (finish_path<SPEC>(A, px, pt, cn)) fl &= ~F_HAVE; else fl |= F_NEWPATH;
+                }
                 need_unit = (fl & F_HAVE) == 0u;
                 if (need_unit) RTW_CEN(cn, CEN_NEED_UNIT);
             }
