@@ -951,6 +951,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC == 2 ?
         // Safety valve of the persistent loop: a wave that has taken an absurd number of scheduler trips (the bench frame needs ~130 k per
         // wave) gives up instead of hanging the GPU; the launch then reports RTW_E_INTERNAL (stats[23] counts such waves).
         if (++trips > RTW_MAX_TRIPS) { aborted = true; break; }
+        RTW_CEN(cn, CEN_BIG_ROOT);                 // (census build: trips through the scheduler)
         const bool run_shade = nS >= RTW_S_HI || (nT < t_lo && nL < t_lo && nS > 0u);
         const bool run_leaf = nL > nT;
 #ifdef RTW_STAMP

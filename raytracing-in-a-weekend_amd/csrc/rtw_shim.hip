@@ -732,7 +732,7 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
         if (getenv("RTW_CENSUS_DUMP")) {
             static const char *names[CEN_N] = { "shading", "inflight (unit(d))", "miss (sky)", "hit (point, normal, material)", "dielectric branch", "schlick draw",
                                                 "diffuse branch", "unit-vector loop trip", "bank store", "needs a work unit", "start_path", "lens-disk loop trip",
-                                                "trav_begin", "depth exhausted", "-", "cooperative round" };
+                                                "trav_begin", "depth exhausted", "trips through the scheduler (all phases)", "cooperative round" };
             std::fprintf(stderr, "rtw census: %llu SHADE steps\n", h_stats[7]);
             for (int k = 0; k < CEN_N; k++)
                 if (h_stats[32 + 2 * k])
