@@ -23,8 +23,9 @@ dst = os.environ.get("PROF_DST", os.path.join(ROOT, "profiles"))
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern), recursive=True)
-    return f[0] if f else None
+    # gpurun MERGES a call's output into gpurun_out/, it does not clear what an earlier call left there: take the NEWEST file of a kind
+    f = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None
 
 
 stats_csv = one("trace/**/*_kernel_stats.csv")
@@ -42,7 +43,12 @@ if trace:
             break
 
 pmc = {}
+_newest = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+    d = os.path.relpath(f, src).split(os.sep)[0]                      # one file per pass directory: the newest (see one())
+    if d not in _newest or os.path.getmtime(f) > os.path.getmtime(_newest[d]):
+        _newest[d] = f
+for f in _newest.values():
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
