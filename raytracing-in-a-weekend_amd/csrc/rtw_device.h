@@ -675,6 +675,7 @@ __device__ __forceinline__ float ln_f32(float xf) {
     return (float)((double)e * 0.6931471805599453094 + lm);
 }
 
+#ifdef RTW_GEOM_EAGER_RECORDS
 // Quad::collision_normal (quad.rs:37-81) against quad `qi` of `quads`; on Some(hit) that is strictly closer
 // than the current one (`min_hit == None || min_hit > i`) it replaces h.
 __device__ __forceinline__ void quad_test(const DevScene &sc, const DevQuad *quads, uint32_t qi, v3 o, v3 d,
@@ -799,6 +800,163 @@ __device__ __forceinline__ bool geom_closest(const DevScene &sc, const DevGeom &
     if (ifound && (!found || h.t > ih.t)) { h = ih; won = true; }
     return won;
 }
+
+#else
+// ---- the closest-hit walk over quads and instances with the `Hit` record formed ONCE, for the winner -------------------------------------
+// The reference fills a whole `Hit` (point, normal, texel, material, emission: 17 words) for every candidate that replaces the current
+// one; what the comparisons read is `t` alone, and `t` is the same number in an instance's local frame and in the world's.  So the walk
+// keeps (t, which member) and the record is rebuilt afterwards with the same operations on the same operands -- bit for bit what the
+// eager form produces (RTW_GEOM_EAGER_RECORDS builds that form; presentation_image A/B in profiles/r03_ab_geom_records.log).
+
+// The tests of Quad::collision_normal (quad.rs:37-63) against quad `qi`: true when it is a Some(hit) that replaces the current one
+// (`min_hit == None || min_hit > i`, strict); t_out = its t.
+__device__ __forceinline__ bool quad_pick(const DevQuad *quads, uint32_t qi, v3 o, v3 d, float mint, float maxt, bool found, float cur_t, float &t_out) {
+    cf4_ptr q = (cf4_ptr)(uintptr_t)(quads + qi);
+    const f4 r0 = q[0], r3 = q[3];
+    const v3 normal = mk(r3.x, r3.y, r3.z);
+    const float denominator = dot(normal, d);
+    if (__builtin_fabsf(denominator) <= 1e-8f) return false;
+    const float numerator = r0.w - dot(normal, o);
+    const float t = numerator / denominator;
+    if (t < mint || t > maxt) return false;
+    if (found && !(cur_t > t)) return false;                   // cannot replace the current hit: skip the interior test
+    const f4 r1 = q[1], r2 = q[2], r4 = q[4];
+    const v3 point = o + d * t;
+    const v3 planar = point - mk(r0.x, r0.y, r0.z);
+    const v3 qu = mk(r1.x, r1.y, r1.z), qv = mk(r2.x, r2.y, r2.z), w = mk(r4.x, r4.y, r4.z);
+    const v3 pxv = mk(planar.y * qv.z - planar.z * qv.y, planar.z * qv.x - planar.x * qv.z, planar.x * qv.y - planar.y * qv.x);
+    const v3 uxp = mk(qu.y * planar.z - qu.z * planar.y, qu.z * planar.x - qu.x * planar.z, qu.x * planar.y - qu.y * planar.x);
+    const float alfa = dot(w, pxv), beta = dot(w, uxp);
+    if (alfa < 0.0f || alfa > 1.0f || beta < 0.0f || beta > 1.0f) return false;
+    t_out = t;
+    return true;
+}
+
+// The `Hit` of quad `qi` at parameter t (quad.rs:64-81); qi is per lane here (vector loads).
+__device__ __forceinline__ void quad_record(const DevScene &sc, const DevQuad *quads, uint32_t qi, v3 o, v3 d, float t, GeomHit &h) {
+    const DevQuad &q = quads[qi];
+    const v3 point = o + d * t;
+    v3 cm = ld3(q.albedo);
+    const int32_t tex = q.tex;
+    if (tex >= 0) {                                            // quad.rs:64-79
+        const v3 planar = point - ld3(q.origin);
+        const v3 qu = ld3(q.u), qv = ld3(q.v), w = ld3(q.w);
+        const v3 pxv = mk(planar.y * qv.z - planar.z * qv.y, planar.z * qv.x - planar.x * qv.z, planar.x * qv.y - planar.y * qv.x);
+        const v3 uxp = mk(qu.y * planar.z - qu.z * planar.y, qu.z * planar.x - qu.x * planar.z, qu.x * planar.y - qu.y * planar.x);
+        const float alfa = dot(w, pxv), beta = dot(w, uxp);
+        const RtwTexture tx = sc.tex[tex];
+        const uint32_t ix = alfa != 1.0f ? tex_index(floorf(alfa * (float)tx.row), tx.row - 1) : tx.row - 1;
+        const uint32_t iy = beta != 1.0f ? tex_index(floorf(beta * (float)tx.col), tx.col - 1) : tx.col - 1;
+        cm = ld3(sc.texels + 3 * (size_t)(tx.texel_offset + iy * tx.row + ix)) * 1.0f;
+    }
+    h.t = t; h.point = point; h.normal = ld3(q.normal); h.cm = cm;
+    h.m = mat_params(q.metallicness, q.opacity, q.ir);
+    h.emitted = ld3(q.emitted);
+}
+
+// Closest member of an instance: its spheres in list order, then its quads (instance.rs:263-273).  code >= 0: member sphere `code`;
+// code < 0: member quad ~code.
+__device__ __forceinline__ bool instance_pick(const DevGeom &g, const DevInstance &in, v3 o, v3 d, float tm, float mint, float maxt,
+                                              float &t_out, int &code, uint32_t &n_sph, uint32_t &n_quad) {
+    int best = -1; float best_t = 0.0f;
+    const float a = dot(d, d);
+    cf4_ptr geom = (cf4_ptr)(uintptr_t)g.igeom, vel = (cf4_ptr)(uintptr_t)g.ivel;
+    for (uint32_t k = 0; k < in.n_spheres; ++k) {              // sphere.rs:99-147, as closest_brute
+        const uint32_t s = in.first_sphere + k;
+        const f4 gg = geom[s], vv = vel[s];
+        const float cx = gg.x + vv.x * tm, cy = gg.y + vv.y * tm, cz = gg.z + vv.z * tm;
+        const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+        const float b = ocx * d.x + ocy * d.y + ocz * d.z;
+        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - gg.w;
+        const float disc = b * b - a * c;
+        if (!(disc < 0.0f)) {
+            const float sq = __builtin_sqrtf(disc);
+            float x = (-b - sq) / a;
+            if (x < mint) x = (-b + sq) / a;
+            if (!(x < mint || x > maxt)) {
+                if (best < 0 || best_t > x) { best = (int)s; best_t = x; }
+            }
+        }
+    }
+    n_sph += in.n_spheres;
+    bool found = best >= 0;
+    for (uint32_t k = 0; k < in.n_quads; ++k) {
+        float t;
+        if (quad_pick(g.iquads, in.first_quad + k, o, d, mint, maxt, found, best_t, t)) { found = true; best_t = t; best = ~(int)(in.first_quad + k); }
+    }
+    n_quad += in.n_quads;
+    t_out = best_t; code = best;
+    return found;
+}
+
+// The `Hit` of an instance's member `code` at parameter t, in the instance's frame.
+__device__ __forceinline__ void member_record(const DevScene &sc, const DevGeom &g, int code, v3 o, v3 d, float tm, float t, GeomHit &h) {
+    if (code >= 0) {
+        const f4 gg = g.igeom[code], vv = g.ivel[code];
+        const v3 c = mk(gg.x, gg.y, gg.z) + mk(vv.x, vv.y, vv.z) * tm;
+        const DevMat mat = g.imat[code];
+        h.t = t; h.point = o + d * t; h.normal = unit(h.point - c);
+        h.cm = sphere_albedo(sc, mat, h.normal);
+        h.m = mat_params(mat);
+        h.emitted = ld3(mat.emitted);
+    } else {
+        quad_record(sc, g.iquads, (uint32_t)~code, o, d, t, h);
+    }
+}
+
+// The part of Scene::collision_normal (viewport.rs:136-150) after the top-level spheres: quads, then instances.
+// `sphere_found` / `sphere_t` are the sphere result; returns true when a quad or an instance wins, h = its Hit.
+__device__ __forceinline__ bool geom_closest(const DevScene &sc, const DevGeom &g, v3 o, v3 d, float tm, float mint, float maxt,
+                                             bool sphere_found, float sphere_t, Rng &rng, GeomHit &h, uint32_t &n_sph, uint32_t &n_quad) {
+    bool found = sphere_found;
+    float ht = sphere_t;
+    int win = 0;                                               // 1: top-level quad qk, 2: instance ii
+    uint32_t qk = 0;
+    {   // q_hit: closest quad first, then compared with s_hit
+        bool qfound = false; float qt = 0.0f;
+        for (uint32_t k = 0; k < g.n_quads; ++k) {
+            float t;
+            if (quad_pick(g.quads, k, o, d, mint, maxt, qfound, qt, t)) { qfound = true; qt = t; qk = k; }
+        }
+        n_quad += g.n_quads;
+        if (qfound && (!found || ht > qt)) { ht = qt; found = true; win = 1; }
+    }
+    bool ifound = false, imed = false;
+    float it = 0.0f; uint32_t ii = 0; int icode = 0;
+    v3 imp = mk(0, 0, 0), imn = mk(0, 0, 0);                   // the medium's scatter point (instance frame) and direction
+    for (uint32_t i = 0; i < g.n_inst; ++i) {                 // Instance::collision_normal (instance.rs:250-310)
+        const DevInstance in = g.inst[i];
+        const v3 tr = ld3(in.tr);
+        const v3 lo = rotated(o - tr, in.back, in.back_k), ld = rotated(d, in.back, in.back_k);
+        float ct; int code;
+        if (!instance_pick(g, in, lo, ld, tm, mint, maxt, ct, code, n_sph, n_quad)) continue;
+        bool med = false; v3 mp = mk(0, 0, 0), mn = mk(0, 0, 0);
+        if (in.medium == RTW_MEDIUM_CONST_DENSITY) {           // const_density (:24-26)
+            const float distance = ln_f32(rng_f32(rng)) / -in.density;
+            if (distance >= 0.0f) {
+                const v3 o2 = (lo + ld * ct) + ld * distance;
+                float t2; int c2;
+                if (!instance_pick(g, in, o2, ld, tm, mint, maxt, t2, c2, n_sph, n_quad)) continue;   // left the volume first
+                med = true; mp = o2; mn = random_unit_vec(rng);
+            }
+        }
+        if (!ifound || it > ct) { it = ct; ii = i; icode = code; imed = med; imp = mp; imn = mn; ifound = true; }
+    }
+    if (ifound && (!found || ht > it)) win = 2;
+    if (win == 1) {
+        quad_record(sc, g.quads, qk, o, d, ht, h);
+    } else if (win == 2) {
+        const DevInstance &in = g.inst[ii];
+        const v3 tr = ld3(in.tr);
+        const v3 lo = rotated(o - tr, in.back, in.back_k), ld = rotated(d, in.back, in.back_k);
+        member_record(sc, g, icode, lo, ld, tm, it, h);
+        if (imed) { h.point = imp; h.normal = imn; }
+        h.point = rotated(h.point, in.fwd, in.fwd_k) + tr;
+        h.normal = rotated(h.normal, in.fwd, in.fwd_k);
+    }
+    return win != 0;
+}
+#endif
 
 // ray_color.rs:38-40
 __device__ __forceinline__ v3 sky_gradient(v3 ud) {      // ud = unit(direction)

@@ -863,6 +863,23 @@ __device__ __forceinline__ void trav_node(const DevBvh &bv, Trav &tr) {
 #ifndef RTW_BVH_WAVES
 #define RTW_BVH_WAVES 4        /* min waves per SIMD the register allocator must leave room for */
 #endif
+// GEOM builds: a ray that is not an ordinary one.  The constant-density medium draws its free path as ln(xi) / -density (instance.rs:24-26),
+// and xi == 0 -- one draw in 2^24, dozens per frame of presentation_image -- makes that +inf: the scatter point, and with it the origin of
+// the next ray, is inf or NaN.  The reference's sphere test ACCEPTS such a ray (every comparison with its NaN root is false,
+// sphere.rs:118-121) and reports the first sphere of the list, where a tree prunes the ray at its root (the tree's bounds presume ordinary
+// operands, DESIGN.md "Conservative traversal"; rtw_shim.hip keeps the camera inside them).  Such lanes walk the list as the reference does;
+// the query is then complete.  (Found as ONE pixel of presentation_image at 64 spp that the tree rendered finite and the list walk NaN:
+// tests/test_gpu_round3.py::test_a_ray_from_infinity_hits_what_the_reference_says.)
+template <bool MOVING, class S>
+__device__ __forceinline__ void wild_ray_query(const KArgs &A, const Path &pt, Trav &tr, uint32_t &n_tests) {
+    const float m = (__builtin_fabsf(pt.o.x) + __builtin_fabsf(pt.o.y) + __builtin_fabsf(pt.o.z)) +
+                    (__builtin_fabsf(pt.d.x) + __builtin_fabsf(pt.d.y) + __builtin_fabsf(pt.d.z));
+    if (m < 0x1p60f) return;
+    closest_brute<MOVING>(A.sc, pt.o, pt.d, pt.tm, A.mint, A.maxt, tr.best, tr.best_t);
+    tr.node = (int)Code<S>::END;
+    n_tests += A.sc.n - A.bvh.n_big;                           // (the big spheres are counted with every query, flush at the kernel's end)
+}
+
 #ifndef RTW_BVH_WAVES_GEOM
 #define RTW_BVH_WAVES_GEOM 2   /* 4 (128 VGPRs, 26 dwords of scratch) measured: no gain */
 #endif
@@ -1071,6 +1088,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC == 2 ?
                         fl |= F_DONE;                                      // banked on the next SHADE trip
                     } else {
                         trav_begin<MOVING, stack_t>(A, pt, tr, lds_addr(lds_raw) + A.lds_stack_off + threadIdx.x * (uint32_t)sizeof(stack_t), a_plain, a_odd, cn);
+                        if constexpr (GEOM) wild_ray_query<MOVING, stack_t>(A, pt, tr, n_isph);
                         fl |= F_INFLIGHT;
                     }
                 }

@@ -441,6 +441,9 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         const double nn = norm(N);
         const double lo = nn > 0.0 ? std::fabs(P[0] * N[0] + P[1] * N[1] + P[2] * N[2]) / nn : 0.0;
         if (!(hi <= 1e15) || !(lo >= 1e-15)) accel = RTW_ACCEL_BRUTE;
+        // ... and that the origin is one: past 2^60 (or NaN) the squares of the quadratic overflow and the same NaN roots appear
+        const double O[3] = { cam->origin[0], cam->origin[1], cam->origin[2] }, CU[3] = { cam->u[0], cam->u[1], cam->u[2] }, CV[3] = { cam->v[0], cam->v[1], cam->v[2] };
+        if (!(norm(O) + std::fabs((double)cam->lens_radius) * (norm(CU) + norm(CV)) <= 0x1p60)) accel = RTW_ACCEL_BRUTE;
         // The tree's bounds cover ray.time in [t_begin, t_end] only (rtw_ctx_set_scene): outside it a moving sphere can leave its box
         if (c->sc.moving) {
             const float ta = cam->time0, tb = cam->time0 + cam->shutter;

@@ -170,3 +170,30 @@ def test_guided_unit_lengths_never_change_the_image(rtw, k):
         part, _ = r.render(cam, p)
         rows = [j for j in range(184) if (j // 8) % 3 == 1]
         assert np.array_equal(part, ref[rows])
+
+
+def test_a_ray_from_infinity_hits_what_the_reference_says(gpu):
+    """presentation_image at 64 spp, sample 53 of pixel (88, 19): the smoke box draws xi == 0 for its free path, ln(0) / -density is
+    +inf, the scatter point -- the next ray's origin -- is not finite, and the reference's sphere test accepts such a ray (its NaN root
+    passes both range tests, sphere.rs:118-121): the path goes on from the sphere and ends NaN.  A tree prunes that ray at its root; the
+    GEOM builds of the traversal kernel therefore walk the list for rays that are not finite.  Until round 3 the tree rendered this
+    pixel finite.  The whole frame: list walk == tree; the row of the event against the oracle."""
+    scene = R.Scene.generate_geom(R.SCENE_PRESENTATION)
+    cam, p = R.default_view(R.SCENE_PRESENTATION)
+    p.samples, p.gamma = 64, 1.0
+    gpu.set_scene(scene)
+    imgs = {}
+    try:
+        for walk_max in (48, 0):                                 # the default (this scene walks the list), and 0: the tree forced
+            gpu.set_option(R.OPT_LIST_WALK_MAX, walk_max)
+            imgs[walk_max] = gpu.render(cam, p)
+    finally:
+        gpu.set_option(R.OPT_LIST_WALK_MAX, 48)
+    (a, sa), (b, sb) = imgs[48], imgs[0]
+    assert np.isnan(a[19, 88]).all() and sa.nan_pixels == sb.nan_pixels
+    assert np.array_equal(a, b, equal_nan=True)
+    assert sa.segments == sb.segments and sa.sphere_tests == sb.sphere_tests and sa.quad_tests == sb.quad_tests
+    q = R.RtwParams.from_buffer_copy(p)
+    q.row_block, q.part_index, q.part_count = 1, 19, 400       # row 19 alone
+    ref, _ = O.render(cam, scene, q, 16)
+    assert np.array_equal(ref.reshape(-1, 400, 3)[0], b[19], equal_nan=True)
