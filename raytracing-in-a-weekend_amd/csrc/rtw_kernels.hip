@@ -382,14 +382,14 @@ __device__ __forceinline__ void start_path_second(const Pixel &px, Path &pt, flo
 
 // Scenes with quads / instances (generic build only): finish Scene::collision_normal (viewport.rs:136-150) for
 // the query whose sphere part returned (best, best_t), then shade whichever object won.
-template <bool MOVING>
+template <bool MOVING, int SPEC>
 __device__ __forceinline__ bool shade_geom(const KArgs &A, Path &pt, int best, float best_t, uint32_t &n_sph, uint32_t &n_quad) {
     GeomHit h;
     if (geom_closest(A.sc, A.geom, pt.o, pt.d, pt.tm, A.mint, A.maxt, best >= 0, best_t, pt.rng, h, n_sph, n_quad)) {
         mat_derive(h.m);
-        return shade_surface<0>(A, pt, unit(pt.d), h.point, h.normal, h.cm, h.m, h.emitted);
+        return shade_surface<SPEC>(A, pt, unit(pt.d), h.point, h.normal, h.cm, h.m, h.emitted);
     }
-    return shade<MOVING, 0>(A, pt, best, best_t);
+    return shade<MOVING, SPEC>(A, pt, best, best_t);
 }
 
 // A path ended: bank its radiance in the sample buffer (the resolve kernel adds the samples of a pixel
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_GEOM_BRUTE_WAVES : 1) void re
                 int best; float best_t;
                 closest_brute<MOVING>(A.sc, pt.o, pt.d, pt.tm, A.mint, A.maxt, best, best_t);
                 n_seg++;
-                finished = GEOM ? shade_geom<MOVING>(A, pt, best, best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, best, best_t);
+                finished = GEOM ? shade_geom<MOVING, SPEC>(A, pt, best, best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, best, best_t);
             }
             if (finished) {
                 if (finish_path<SPEC>(A, px, pt)) have = false;
@@ -881,7 +881,10 @@ __device__ __forceinline__ void wild_ray_query(const KArgs &A, const Path &pt, T
 }
 
 #ifndef RTW_BVH_WAVES_GEOM
-#define RTW_BVH_WAVES_GEOM 2   /* 4 (128 VGPRs, 26 dwords of scratch) measured: no gain */
+#define RTW_BVH_WAVES_GEOM 2   /* the generic GEOM builds (114 VGPRs, 4 waves as compiled); 3 / 4 / 5 / 6 measured, profiles/r03_ab_geom_waves.log */
+#endif
+#ifndef RTW_BVH_WAVES_GEOM_SPEC
+#define RTW_BVH_WAVES_GEOM_SPEC 5   /* the GEOM builds of the common configuration (SPEC == 2; 97 - 104 VGPRs uncapped): profiles/r03_ab_geom_spec.log */
 #endif
 #ifndef RTW_BVH_WAVES_SPEC
 #define RTW_BVH_WAVES_SPEC 7   /* the specialised builds (SPEC != 0) are compiled for 7 waves/SIMD = 72 VGPRs (two dwords of scratch in the static builds, ten in the MOVING
@@ -893,7 +896,7 @@ __device__ __forceinline__ void wild_ray_query(const KArgs &A, const Path &pt, T
 // NODES: 0 = f32 nodes in global memory, 32-bit stack; 1 = f16 nodes in LDS, 16-bit stack; 2 = as 1, and the spheres' {centre, r^2} in LDS
 // too (a build of its own: as a run-time choice the leaf test went through a flat load and a select of two addresses, 7 VALU).
 template <bool MOVING, int NODES, int SPEC, bool GEOM>
-__global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC == 2 ? RTW_BVH_WAVES_SPEC2 : (SPEC != 0 ? RTW_BVH_WAVES_SPEC : RTW_BVH_WAVES))) void render_bvh(const KArgs A) {
+__global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_SPEC : RTW_BVH_WAVES_GEOM) : (SPEC == 2 ? RTW_BVH_WAVES_SPEC2 : (SPEC != 0 ? RTW_BVH_WAVES_SPEC : RTW_BVH_WAVES))) void render_bvh(const KArgs A) {
     constexpr bool LDSN = NODES != 0, geom_in_lds = NODES == 2;
     // LDS is all dynamic, sized by the host for THIS tree (rtw_shim.hip, render_enqueue_impl): -- LDS-node variants -- the f16 nodes at
     // offset 0, then the per-lane traversal stack [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel,
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? RTW_BVH_WAVES_GEOM : (SPEC == 2 ?
                 RTW_CEN(cn, CEN_SHADING);
                 if (fl & F_INFLIGHT) {
                     fl &= ~F_INFLIGHT;
-                    const bool done = GEOM ? shade_geom<MOVING>(A, pt, tr.best, tr.best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t, cn);
+                    const bool done = GEOM ? shade_geom<MOVING, SPEC>(A, pt, tr.best, tr.best_t, n_isph, n_quad) : shade<MOVING, SPEC>(A, pt, tr.best, tr.best_t, cn);
                     if (done) fl |= F_DONE;
                 }
             }
@@ -1215,17 +1218,24 @@ static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, int nodes) {
     }
     return moving ? render_brute<true, SPEC, false> : render_brute<false, SPEC, false>;
 }
-// quads / instances in the scene: the generic build with the extra closest-hit stage (sphere geometry always global: kernel_has_lds_geom)
+// quads / instances in the scene: the step of the generic build (SPEC == 0: everything from the kernel arguments; SPEC == 2: the common configuration folded
+// in at compile time, sphere textures kept) with the extra closest-hit stage (sphere geometry always global: kernel_has_lds_geom)
+template <int SPEC>
 static kernel_fn pick_kernel_geom(bool moving, uint32_t accel, int nodes) {
     if (accel == RTW_ACCEL_BVH) {
-        if (nodes) return moving ? render_bvh<true, 1, 0, true> : render_bvh<false, 1, 0, true>;
-        return moving ? render_bvh<true, 0, 0, true> : render_bvh<false, 0, 0, true>;
+        if (nodes) return moving ? render_bvh<true, 1, SPEC, true> : render_bvh<false, 1, SPEC, true>;
+        return moving ? render_bvh<true, 0, SPEC, true> : render_bvh<false, 0, SPEC, true>;
     }
-    return moving ? render_brute<true, 0, true> : render_brute<false, 0, true>;
+    return moving ? render_brute<true, SPEC, true> : render_brute<false, SPEC, true>;
 }
 static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool lds_nodes) {
     const int nodes = lds_nodes ? (a.lds_geom_off ? 2 : 1) : 0;
-    if (a.geom.n_quads || a.geom.n_inst) return pick_kernel_geom(moving, accel, nodes);
+    if (a.geom.n_quads || a.geom.n_inst) {
+#ifndef RTW_GEOM_GENERIC_ONLY
+        if (is_common_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<2>(moving, accel, nodes);
+#endif
+        return pick_kernel_geom<0>(moving, accel, nodes);
+    }
     if (!is_common_config(a)) return pick_kernel_spec<0>(moving, accel, nodes);
     if (a.flags & RTW_FLAG_CHUNK_SUMS) return a.has_textures ? pick_kernel_spec<0>(moving, accel, nodes) : pick_kernel_spec<3>(moving, accel, nodes);
     return a.has_textures ? pick_kernel_spec<2>(moving, accel, nodes) : pick_kernel_spec<1>(moving, accel, nodes);

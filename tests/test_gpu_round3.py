@@ -197,3 +197,31 @@ def test_a_ray_from_infinity_hits_what_the_reference_says(gpu):
     q.row_block, q.part_index, q.part_count = 1, 19, 400       # row 19 alone
     ref, _ = O.render(cam, scene, q, 16)
     assert np.array_equal(ref.reshape(-1, 400, 3)[0], b[19], equal_nan=True)
+
+
+@pytest.mark.parametrize("integrator", ["gradient", "bg_color"])
+def test_book1_with_quads_and_a_medium_through_the_tree(gpu, integrator):
+    """The scene that runs the GEOM builds of the traversal kernel as shipped: the Book-1 final scene's 485 spheres through the tree, three quads (a light,
+    a mirror, a glass pane) and a rotated smoke box walked in the SHADE step.  `gradient` with the render_row sampler is the common configuration, which since
+    round 3 has GEOM builds of its own (integrator / sampler folded in at compile time, SPEC == 2); `bg_color` runs the generic GEOM build.  Bit-exact against the
+    oracle, tree and list walk alike."""
+    base = R.Scene.generate(R.SCENE_C2, 42)
+    spheres = [R.RtwSphere.from_buffer_copy(base._spheres[i]) for i in range(base.n_spheres)]
+    quads = [R.Quad.new((-2.0, 6.0, -2.0), (4, 0, 0), (0, 0, 4), (0.0, 0.0, 1.0), (1, 1, 1), emitted=(7, 7, 7)),
+             R.Quad.new((-8.0, 0.0, -9.0), (16, 0, 0), (0, 5, 0), R.METALLIC_M, (0.8, 0.85, 0.88)),
+             R.Quad.new((2.0, 0.0, 2.5), (1.5, 0, -1.0), (0, 1.5, 0), R.GLASS_M, (1, 1, 1))]
+    box = R.Instance.new_box((-1.0, 0.0, -1.0), (1.0, 1.6, 1.0), (0.9, 0.9, 0.9), R.SCATTER_M)
+    box.rotate((0.0, 0.5, 0.0)); box.translate((-3.0, 0.0, 3.0)); box.const_density(0.8)
+    scene = R.Scene(spheres, background=(0.5, 0.7, 1.0), quads=quads, instances=[box])
+    cam, p = R.default_view(R.SCENE_C2)
+    p.samples, p.gamma = 4, 1.0                                          # the frame's own camera (1200 x 675); 4 spp keeps the oracle at seconds
+    p.integrator = R.INTEGRATOR_GRADIENT if integrator == "gradient" else R.INTEGRATOR_BG_COLOR
+    q = R.RtwParams.from_buffer_copy(p)
+    q.row_block, q.part_index, q.part_count = 8, 3, 12                   # every twelfth block of 8 rows: 56 rows spread over the frame
+    ref, st_ref = O.render(cam, scene, q, 16)
+    gpu.set_scene(scene)
+    for accel in (R.ACCEL_BVH, R.ACCEL_BRUTE):
+        q.accel = accel
+        img, st = gpu.render(cam, q)
+        assert st.segments == st_ref.segments and st.quad_tests == st_ref.quad_tests, accel
+        assert np.array_equal(img, ref, equal_nan=True), accel
