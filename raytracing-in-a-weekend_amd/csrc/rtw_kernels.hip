@@ -46,8 +46,11 @@ namespace rtw {
 // that no sphere carries an image texture (no atan2f/acosf code at all); SPEC == 2 keeps the texture lookup (C5).
 // SPEC == 3 is SPEC == 1 with RTW_FLAG_CHUNK_SUMS (one partial sum per work unit in the bank); the generic build honours the flag at run
 // time; a runtime test of it in the SPEC == 1 / 2 builds cost the bench frame 0.8 % (gpurun_out/r02_ab_chunk.log), hence a build of its own.
+// SPEC == 4 (GEOM builds only) is the reference's own demo configuration, presentation_image (main.rs:89-419): ray_color_bg_color with the render_row sampler.
 // SPEC == 0 reads everything from the (wave-uniform) kernel arguments.
-template <int SPEC> __device__ __forceinline__ uint32_t integ(const KArgs &A) { return SPEC ? (uint32_t)RTW_INTEGRATOR_GRADIENT : A.integrator; }
+template <int SPEC> __device__ __forceinline__ uint32_t integ(const KArgs &A) {
+    return SPEC == 4 ? (uint32_t)RTW_INTEGRATOR_BG_COLOR : SPEC ? (uint32_t)RTW_INTEGRATOR_GRADIENT : A.integrator;
+}
 template <int SPEC> __device__ __forceinline__ uint32_t samp(const KArgs &A) { return SPEC ? (uint32_t)RTW_SAMPLER_ROW : A.sampler; }
 
 struct Pixel {            // the work unit a lane owns: a run of consecutive samples of one pixel.  Four registers (they live through every step of
@@ -269,7 +272,7 @@ __device__ __forceinline__ void shade_miss(const KArgs &A, Path &pt, v3 ud) {
     else miss = sky_gradient(ud);
     // SPEC builds (ray_color_gradient): nothing has been gathered before the path ends, pt.L is 0 -- so L is not carried from step to step -- and
     // the oracle's `0 + x` is x itself except for x = -0, which the resolve pass's own `0 + ..` (the pixel's sum starts at +0) turns into the same +0
-    if (SPEC) pt.L = miss * pt.thr;
+    if (SPEC != 0 && SPEC != 4) pt.L = miss * pt.thr;
     else pt.L = pt.L + miss * pt.thr;
 }
 
@@ -1209,6 +1212,10 @@ static bool is_common_config(const KArgs &a) {
     return a.integrator == RTW_INTEGRATOR_GRADIENT && a.sampler == RTW_SAMPLER_ROW && a.depth >= 1 &&
            (a.flags & (RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE)) == 0u;
 }
+static bool is_demo_config(const KArgs &a) {                   // presentation_image's: ray_color_bg_color through render_row
+    return a.integrator == RTW_INTEGRATOR_BG_COLOR && a.sampler == RTW_SAMPLER_ROW && a.depth >= 1 &&
+           (a.flags & (RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE)) == 0u;
+}
 template <int SPEC>
 static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, int nodes) {
     if (accel == RTW_ACCEL_BVH) {
@@ -1233,6 +1240,7 @@ static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool l
     if (a.geom.n_quads || a.geom.n_inst) {
 #ifndef RTW_GEOM_GENERIC_ONLY
         if (is_common_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<2>(moving, accel, nodes);
+        if (is_demo_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<4>(moving, accel, nodes);
 #endif
         return pick_kernel_geom<0>(moving, accel, nodes);
     }
