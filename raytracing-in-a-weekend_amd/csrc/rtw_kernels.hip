@@ -46,12 +46,16 @@ namespace rtw {
 // that no sphere carries an image texture (no atan2f/acosf code at all); SPEC == 2 keeps the texture lookup (C5).
 // SPEC == 3 is SPEC == 1 with RTW_FLAG_CHUNK_SUMS (one partial sum per work unit in the bank); the generic build honours the flag at run
 // time; a runtime test of it in the SPEC == 1 / 2 builds cost the bench frame 0.8 % (gpurun_out/r02_ab_chunk.log), hence a build of its own.
-// SPEC == 4 (GEOM builds only) is the reference's own demo configuration, presentation_image (main.rs:89-419): ray_color_bg_color with the render_row sampler.
+// SPEC == 4 is the reference's own demo configuration, presentation_image (main.rs:89-419): ray_color_bg_color with the render_row sampler; SPEC == 5 is
+// Rust2's: its `ray_color` through its fixed-centre `render_row` (Rust2/src/viewport.rs:87-114).  Both keep the generic build's step and fold the switches.
 // SPEC == 0 reads everything from the (wave-uniform) kernel arguments.
+constexpr bool gradient_spec(int spec) { return spec >= 1 && spec <= 3; }
 template <int SPEC> __device__ __forceinline__ uint32_t integ(const KArgs &A) {
-    return SPEC == 4 ? (uint32_t)RTW_INTEGRATOR_BG_COLOR : SPEC ? (uint32_t)RTW_INTEGRATOR_GRADIENT : A.integrator;
+    return SPEC == 5 ? (uint32_t)RTW_INTEGRATOR_RUST2 : SPEC == 4 ? (uint32_t)RTW_INTEGRATOR_BG_COLOR : SPEC ? (uint32_t)RTW_INTEGRATOR_GRADIENT : A.integrator;
 }
-template <int SPEC> __device__ __forceinline__ uint32_t samp(const KArgs &A) { return SPEC ? (uint32_t)RTW_SAMPLER_ROW : A.sampler; }
+template <int SPEC> __device__ __forceinline__ uint32_t samp(const KArgs &A) {
+    return SPEC == 5 ? (uint32_t)RTW_SAMPLER_CENTRES : SPEC ? (uint32_t)RTW_SAMPLER_ROW : A.sampler;
+}
 
 struct Pixel {            // the work unit a lane owns: a run of consecutive samples of one pixel.  Four registers (they live through every step of
                           // the persistent loop, and the specialised builds have 72): the shim keeps width, height < 2^16, samples < 2^24, units <= 255 samples
@@ -272,7 +276,7 @@ __device__ __forceinline__ void shade_miss(const KArgs &A, Path &pt, v3 ud) {
     else miss = sky_gradient(ud);
     // SPEC builds (ray_color_gradient): nothing has been gathered before the path ends, pt.L is 0 -- so L is not carried from step to step -- and
     // the oracle's `0 + x` is x itself except for x = -0, which the resolve pass's own `0 + ..` (the pixel's sum starts at +0) turns into the same +0
-    if (SPEC != 0 && SPEC != 4) pt.L = miss * pt.thr;
+    if (gradient_spec(SPEC)) pt.L = miss * pt.thr;
     else pt.L = pt.L + miss * pt.thr;
 }
 
@@ -328,7 +332,7 @@ __device__ __forceinline__ bool shade_hit(const KArgs &A, Path &pt, v3 ud, int b
     const v3 normal = unit(point - c);                       // sphere.rs:127
     const DevMat mat = sc.mat[best];
     v3 cm, emitted = ld3(mat.emitted);
-    if (!SPEC && A.integrator == RTW_INTEGRATOR_RUST2 && mat.tex >= 0) rust2_sphere_color(sc, mat, normal, cm, emitted);     // Rust2's own lookup rule
+    if ((SPEC == 0 || SPEC == 5) && integ<SPEC>(A) == RTW_INTEGRATOR_RUST2 && mat.tex >= 0) rust2_sphere_color(sc, mat, normal, cm, emitted);     // Rust2's own lookup rule
     else cm = (SPEC == 1 || SPEC == 3) ? ld3(mat.cm) : sphere_albedo(sc, mat, normal);
     return shade_surface<SPEC>(A, pt, ud, point, normal, cm, mat_params(mat), emitted, cn);
 }
@@ -898,8 +902,19 @@ __device__ __forceinline__ void wild_ray_query(const KArgs &A, const Path &pt, T
 #endif
 // NODES: 0 = f32 nodes in global memory, 32-bit stack; 1 = f16 nodes in LDS, 16-bit stack; 2 = as 1, and the spheres' {centre, r^2} in LDS
 // too (a build of its own: as a run-time choice the leaf test went through a flat load and a select of two addresses, 7 VALU).
+// Which builds run the SHADE step in two halves around one rejection loop (4.2): the common configuration without quads / instances.
+#ifndef RTW_BVH_WAVES_FOLDED
+#define RTW_BVH_WAVES_FOLDED RTW_BVH_WAVES   /* builds with the generic step and folded switches (SPEC == 4 without GEOM) */
+#endif
+constexpr bool two_halves_step(int spec, bool geom) {
+#ifdef RTW_NO_TWO_HALVES
+    return false;
+#else
+    return gradient_spec(spec) && !geom;
+#endif
+}
 template <bool MOVING, int NODES, int SPEC, bool GEOM>
-__global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_SPEC : RTW_BVH_WAVES_GEOM) : (SPEC == 2 ? RTW_BVH_WAVES_SPEC2 : (SPEC != 0 ? RTW_BVH_WAVES_SPEC : RTW_BVH_WAVES))) void render_bvh(const KArgs A) {
+__global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_SPEC : RTW_BVH_WAVES_GEOM) : (two_halves_step(SPEC, GEOM) ? (SPEC == 2 ? RTW_BVH_WAVES_SPEC2 : RTW_BVH_WAVES_SPEC) : (SPEC != 0 ? RTW_BVH_WAVES_FOLDED : RTW_BVH_WAVES))) void render_bvh(const KArgs A) {
     constexpr bool LDSN = NODES != 0, geom_in_lds = NODES == 2;
     // LDS is all dynamic, sized by the host for THIS tree (rtw_shim.hip, render_enqueue_impl): -- LDS-node variants -- the f16 nodes at
     // offset 0, then the per-lane traversal stack [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel,
@@ -991,7 +1006,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_S
 #ifdef RTW_STAMP
             t_sub = t_begin;
 #endif
-            if constexpr (SPEC != 0 && !GEOM) {
+            if constexpr (two_halves_step(SPEC, GEOM)) {
             // ---- specialised builds: the step in two halves around one rejection loop for the scatter directions AND the lens samples ----
             bool need_ball = false, need_disk = false, front = false;
             // a. the closest-hit query this lane was waiting on is complete.  Paths that END here -- the ray missed (sky), or its depth is
@@ -1216,6 +1231,10 @@ static bool is_demo_config(const KArgs &a) {                   // presentation_i
     return a.integrator == RTW_INTEGRATOR_BG_COLOR && a.sampler == RTW_SAMPLER_ROW && a.depth >= 1 &&
            (a.flags & (RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE)) == 0u;
 }
+static bool is_rust2_config(const KArgs &a) {                  // Rust2's: ray_color through its fixed-centre render_row
+    return a.integrator == RTW_INTEGRATOR_RUST2 && a.sampler == RTW_SAMPLER_CENTRES && a.depth >= 1 &&
+           (a.flags & (RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE)) == 0u;
+}
 template <int SPEC>
 static kernel_fn pick_kernel_spec(bool moving, uint32_t accel, int nodes) {
     if (accel == RTW_ACCEL_BVH) {
@@ -1241,9 +1260,14 @@ static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool l
 #ifndef RTW_GEOM_GENERIC_ONLY
         if (is_common_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<2>(moving, accel, nodes);
         if (is_demo_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<4>(moving, accel, nodes);
+        if (is_rust2_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<5>(moving, accel, nodes);
 #endif
         return pick_kernel_geom<0>(moving, accel, nodes);
     }
+#ifndef RTW_GEOM_GENERIC_ONLY
+    if (is_demo_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_spec<4>(moving, accel, nodes);    // (the generic build's step, switches folded in)
+    if (is_rust2_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_spec<5>(moving, accel, nodes);
+#endif
     if (!is_common_config(a)) return pick_kernel_spec<0>(moving, accel, nodes);
     if (a.flags & RTW_FLAG_CHUNK_SUMS) return a.has_textures ? pick_kernel_spec<0>(moving, accel, nodes) : pick_kernel_spec<3>(moving, accel, nodes);
     return a.has_textures ? pick_kernel_spec<2>(moving, accel, nodes) : pick_kernel_spec<1>(moving, accel, nodes);

@@ -19,14 +19,19 @@ cam, p = R.default_view(R.SCENE_C2)
 r = R.Renderer(0)
 out = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device="cuda:0")
 cases = (("spheres only, gradient (specialised build)", R.INTEGRATOR_GRADIENT, [], []),
-         ("spheres only, bg_color (generic build)", R.INTEGRATOR_BG_COLOR, [], []),
+         ("spheres only, bg_color (the generic step, switches folded in)", R.INTEGRATOR_BG_COLOR, [], []),
          ("+ 3 quads", R.INTEGRATOR_GRADIENT, quads(), []),
          ("+ 1 quad", R.INTEGRATOR_GRADIENT, quads()[:1], []),
          ("+ a box instance (6 quads)", R.INTEGRATOR_GRADIENT, [], [box(False)]),
          ("+ the box as a medium", R.INTEGRATOR_GRADIENT, [], [box(True)]),
          ("+ 3 quads + the medium", R.INTEGRATOR_GRADIENT, quads(), [box(True)]))
+import numpy as np
+cam2 = R.camera2_new(np.float32(p.width) / np.float32(p.height), (13, 2, 3), (0, 1, 0), (-13 / 13.49, -2 / 13.49, -3 / 13.49), 20.0, 0.05)   # Rust2's Camera on the same view
+cases += (("spheres only, Rust2's ray_color + render_row", R.INTEGRATOR_RUST2, [], []),)
+cam1, sampler1 = cam, p.sampler
 for name, integ, q, inst in cases:
     scene = R.Scene(spheres, background=(0.5, 0.7, 1.0), quads=q, instances=inst)
+    cam, p.sampler = (cam2, R.SAMPLER_CENTRES) if integ == R.INTEGRATOR_RUST2 else (cam1, sampler1)
     r.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
     p.integrator = integ
     r.render(cam, p, out=out.data_ptr())
