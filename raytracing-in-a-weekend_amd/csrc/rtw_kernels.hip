@@ -976,6 +976,8 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_S
 #ifdef RTW_ENDTIMES
     const unsigned long long t_wave_start = __builtin_amdgcn_s_memtime();
     const unsigned long long rt_wave_start = wall_clock64();     // s_memrealtime: one 100 MHz clock for the whole device (s_memtime is per XCD)
+    uint32_t dry_trips = 0, dry_steps[3] = { 0, 0, 0 }, dry_lanes[3] = { 0, 0, 0 };   // what the wave does after it has found the queue empty
+    uint32_t dry_queries = 0;                                                          // per lane: queries shaded after that
 #endif
     for (;;) {
         // ---- scheduler ---------------------------------------------------------------------------
@@ -992,6 +994,14 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_S
         RTW_CEN(cn, CEN_BIG_ROOT);                 // (census build: trips through the scheduler)
         const bool run_shade = nS >= RTW_S_HI || (nT < t_lo && nL < t_lo && nS > 0u);
         const bool run_leaf = nL > nT;
+#ifdef RTW_ENDTIMES
+        if (rs.t_dry) {
+            dry_trips++;
+            const int ph = run_shade ? 2 : (run_leaf ? 1 : 0);
+            dry_steps[ph]++; dry_lanes[ph] += ph == 2 ? nS : (ph == 1 ? nL : nT);
+            if (run_shade && in_shade<stack_t>(tr.node) && (fl & F_INFLIGHT)) dry_queries++;
+        }
+#endif
 #ifdef RTW_STAMP
         const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
         const int which = run_shade ? 2 : (run_leaf ? 1 : 0);
@@ -1187,6 +1197,10 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_S
         if ((threadIdx.x & 63u) == 0) { atomicAdd(&A.stats[32 + 2 * k], w); atomicAdd(&A.stats[33 + 2 * k], n); }
     }
 #endif
+#ifdef RTW_ENDTIMES
+    uint32_t dry_q_max = dry_queries, dry_q_sum = dry_queries;
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(dry_q_max, off); dry_q_max = o > dry_q_max ? o : dry_q_max; dry_q_sum += __shfl_down(dry_q_sum, off); }
+#endif
     if ((threadIdx.x & 63u) == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)w_rays);
         atomicAdd(&A.stats[1], (unsigned long long)w_seg);
@@ -1215,6 +1229,11 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_S
         atomicMin(&A.stats[26], rt_end);                   // [26] earliest wave end
         atomicMax(&A.stats[27], rt_end);                   // [27] latest wave end
         if (rs.t_dry) { atomicMin(&A.stats[28], rs.t_dry); atomicMax(&A.stats[29], rs.t_dry); atomicMax(&A.stats[30], rt_end - rs.t_dry); atomicAdd(&A.stats[31], rt_end - rs.t_dry); }
+        if (rs.t_dry && rt_end - rs.t_dry >= 60000ull) {   // the waves that ran on for 0.6 ms or more: [40] how many, [41] ticks, [42] trips, [43..45] steps T / L / S, [46..48] their lanes, [49] max queries of a lane, [50] sum
+            atomicAdd(&A.stats[40], 1ull); atomicAdd(&A.stats[41], rt_end - rs.t_dry); atomicAdd(&A.stats[42], (unsigned long long)dry_trips);
+            for (int k = 0; k < 3; k++) { atomicAdd(&A.stats[43 + k], (unsigned long long)dry_steps[k]); atomicAdd(&A.stats[46 + k], (unsigned long long)dry_lanes[k]); }
+            atomicAdd(&A.stats[49], (unsigned long long)dry_q_max); atomicAdd(&A.stats[50], (unsigned long long)dry_q_sum);
+        }
 #endif
     }
 }

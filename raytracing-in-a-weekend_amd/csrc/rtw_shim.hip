@@ -759,6 +759,13 @@ static int render_wait(rtw_ctx *c, RtwStats *stats) {
             std::fprintf(stderr, "rtw endtimes: the queue ran dry for the first wave %.1f us and for the last wave %.1f us after the first start; a wave then ran on for %.1f us on average, %.1f us at most\n",
                          (double)(h_stats[28] - h_stats[24]) / 100.0, (double)(h_stats[29] - h_stats[24]) / 100.0, (double)h_stats[31] / (double)h_stats[15] / 100.0, (double)h_stats[30] / 100.0);
         if (getenv("RTW_ENDTIMES_DUMP") && h_stats[15]) {   // RTW_ENDTIMES build: [12] longest wave lifetime [13] sum of wave lifetimes [15] waves
+            if (h_stats[40]) {
+                const double n = (double)h_stats[40];
+                std::fprintf(stderr, "rtw endtimes: %llu waves ran on for 0.6 ms or more after finding the queue empty: on average %.0f us, %.0f scheduler trips (%.0f TRAVERSE steps with %.1f lanes, %.0f LEAF with %.1f, %.0f SHADE with %.1f), the busiest lane shaded %.1f queries, all lanes %.1f -> %.1f us per trip, %.1f us per query of the busiest lane\n",
+                             h_stats[40], h_stats[41] / n / 100.0, h_stats[42] / n, h_stats[43] / n, h_stats[43] ? (double)h_stats[46] / h_stats[43] : 0.0, h_stats[44] / n, h_stats[44] ? (double)h_stats[47] / h_stats[44] : 0.0,
+                             h_stats[45] / n, h_stats[45] ? (double)h_stats[48] / h_stats[45] : 0.0, h_stats[49] / n, h_stats[50] / n,
+                             h_stats[42] ? h_stats[41] / 100.0 / h_stats[42] : 0.0, h_stats[49] ? h_stats[41] / 100.0 / h_stats[49] : 0.0);
+            }
             std::fprintf(stderr, "rtw endtimes: %llu waves, longest lifetime %llu ticks, mean lifetime %.1f %% of it\n", h_stats[15], h_stats[12],
                          100.0 * (double)h_stats[13] / (double)h_stats[15] / (double)h_stats[12]);
         }

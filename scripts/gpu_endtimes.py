@@ -8,6 +8,8 @@ scene = R.Scene.generate(R.SCENE_C2, 42)
 cam, p = R.default_view(R.SCENE_C5); cam.shutter = 0.0
 r = R.Renderer(0); r.set_scene(scene)
 if os.environ.get("TAIL"): r.set_option(R.OPT_TAIL_UNITS, float(os.environ["TAIL"]))
+if os.environ.get("ORDER"): r.set_option(R.OPT_TILE_ORDER, float(os.environ["ORDER"]))
+if os.environ.get("WGS"): r.set_option(R.OPT_BLOCKS_PER_CU, float(os.environ["WGS"]))
 if os.environ.get("CHUNK"): r.set_option(R.OPT_CHUNK_LEN, float(os.environ["CHUNK"]))
 out = torch.zeros((1080, 1920, 3), dtype=torch.float32, device="cuda:0")
 which = [int(x) for x in os.environ.get("PARTS", "1,8,64").split(",")]
