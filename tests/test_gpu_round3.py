@@ -197,6 +197,17 @@ def test_a_ray_from_infinity_hits_what_the_reference_says(gpu):
     q.row_block, q.part_index, q.part_count = 1, 19, 400       # row 19 alone
     ref, _ = O.render(cam, scene, q, 16)
     assert np.array_equal(ref.reshape(-1, 400, 3)[0], b[19], equal_nan=True)
+    # ... and the frame as the reference renders it (2500 spp: ~60 such paths): one image from both kernels
+    cam, p = R.default_view(R.SCENE_PRESENTATION)
+    try:
+        full = {}
+        for walk_max in (48, 0):
+            gpu.set_option(R.OPT_LIST_WALK_MAX, walk_max)
+            full[walk_max] = gpu.render(cam, p)
+    finally:
+        gpu.set_option(R.OPT_LIST_WALK_MAX, 48)
+    assert full[48][1].nan_pixels == full[0][1].nan_pixels and full[48][1].segments == full[0][1].segments
+    assert np.array_equal(full[48][0], full[0][0], equal_nan=True)
 
 
 @pytest.mark.parametrize("integrator", ["gradient", "bg_color"])
