@@ -276,6 +276,11 @@ def test_c3_full_size_properties(gpu):
     half, st_half = gpu.render(cam, p)
     rows = [r for r in range(1080) if (r // 8) % 2 == 1]
     assert np.array_equal(full[rows], half)
+    # ... and the list walk renders the same frame, bit for bit (BVH == brute force at the headline size)
+    p.row_block, p.part_index, p.part_count = 1, 0, 1
+    p.accel = R.ACCEL_BRUTE
+    brute, st_b = gpu.render(cam, p)
+    assert st_b.segments == st.segments and np.array_equal(full, brute)
 
 
 def test_rust2_model_bit_exact(gpu):
