@@ -906,15 +906,17 @@ __device__ __forceinline__ void wild_ray_query(const KArgs &A, const Path &pt, T
 #ifndef RTW_BVH_WAVES_FOLDED
 #define RTW_BVH_WAVES_FOLDED RTW_BVH_WAVES   /* builds with the generic step and folded switches (SPEC == 4 without GEOM) */
 #endif
-constexpr bool two_halves_step(int spec, bool geom) {
+// (Not the MOVING build that keeps the texture lookup -- C5's: there the generic-shaped step with the switches folded in is level or ahead, 92.9 / 93.1 against
+//  93.6 / 93.9 ms at 7 waves, profiles/r03_ab_two_halves_c5*.log -- the two-halves step's spills at 72 VGPRs eat what it saves.)
+constexpr bool two_halves_step(int spec, bool geom, bool moving) {
 #ifdef RTW_NO_TWO_HALVES
     return false;
 #else
-    return gradient_spec(spec) && !geom;
+    return gradient_spec(spec) && !geom && !(moving && spec == 2);
 #endif
 }
 template <bool MOVING, int NODES, int SPEC, bool GEOM>
-__global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_SPEC : RTW_BVH_WAVES_GEOM) : (two_halves_step(SPEC, GEOM) ? (SPEC == 2 ? RTW_BVH_WAVES_SPEC2 : RTW_BVH_WAVES_SPEC) : (SPEC != 0 ? RTW_BVH_WAVES_FOLDED : RTW_BVH_WAVES))) void render_bvh(const KArgs A) {
+__global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_SPEC : RTW_BVH_WAVES_GEOM) : (two_halves_step(SPEC, GEOM, MOVING) ? (SPEC == 2 ? RTW_BVH_WAVES_SPEC2 : RTW_BVH_WAVES_SPEC) : (gradient_spec(SPEC) ? RTW_BVH_WAVES_SPEC2 : (SPEC != 0 ? RTW_BVH_WAVES_FOLDED : RTW_BVH_WAVES)))) void render_bvh(const KArgs A) {
     constexpr bool LDSN = NODES != 0, geom_in_lds = NODES == 2;
     // LDS is all dynamic, sized by the host for THIS tree (rtw_shim.hip, render_enqueue_impl): -- LDS-node variants -- the f16 nodes at
     // offset 0, then the per-lane traversal stack [level][thread] (a level is one conflict-free row; depth + 3 levels: the sentinel,
@@ -1016,7 +1018,7 @@ __global__ __launch_bounds__(RTW_BLOCK, GEOM ? (SPEC != 0 ? RTW_BVH_WAVES_GEOM_S
 #ifdef RTW_STAMP
             t_sub = t_begin;
 #endif
-            if constexpr (two_halves_step(SPEC, GEOM)) {
+            if constexpr (two_halves_step(SPEC, GEOM, MOVING)) {
             // ---- specialised builds: the step in two halves around one rejection loop for the scatter directions AND the lens samples ----
             bool need_ball = false, need_disk = false, front = false;
             // a. the closest-hit query this lane was waiting on is complete.  Paths that END here -- the ray missed (sky), or its depth is
