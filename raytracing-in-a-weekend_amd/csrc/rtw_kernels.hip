@@ -47,14 +47,15 @@ namespace rtw {
 // SPEC == 3 is SPEC == 1 with RTW_FLAG_CHUNK_SUMS (one partial sum per work unit in the bank); the generic build honours the flag at run
 // time; a runtime test of it in the SPEC == 1 / 2 builds cost the bench frame 0.8 % (gpurun_out/r02_ab_chunk.log), hence a build of its own.
 // SPEC == 4 is the reference's own demo configuration, presentation_image (main.rs:89-419): ray_color_bg_color with the render_row sampler; SPEC == 5 is
-// Rust2's: its `ray_color` through its fixed-centre `render_row` (Rust2/src/viewport.rs:87-114).  Both keep the generic build's step and fold the switches.
+// Rust2's: its `ray_color` through its fixed-centre `render_row` (Rust2/src/viewport.rs:87-114); SPEC == 6 is ray_color_gradient through the stratified
+// `Viewport::render` (viewport.rs:430-478: the reference's serial driver, quad_test's).  All three keep the generic build's step and fold the switches.
 // SPEC == 0 reads everything from the (wave-uniform) kernel arguments.
 constexpr bool gradient_spec(int spec) { return spec >= 1 && spec <= 3; }
 template <int SPEC> __device__ __forceinline__ uint32_t integ(const KArgs &A) {
     return SPEC == 5 ? (uint32_t)RTW_INTEGRATOR_RUST2 : SPEC == 4 ? (uint32_t)RTW_INTEGRATOR_BG_COLOR : SPEC ? (uint32_t)RTW_INTEGRATOR_GRADIENT : A.integrator;
 }
 template <int SPEC> __device__ __forceinline__ uint32_t samp(const KArgs &A) {
-    return SPEC == 5 ? (uint32_t)RTW_SAMPLER_CENTRES : SPEC ? (uint32_t)RTW_SAMPLER_ROW : A.sampler;
+    return SPEC == 6 ? (uint32_t)RTW_SAMPLER_STRATIFIED : SPEC == 5 ? (uint32_t)RTW_SAMPLER_CENTRES : SPEC ? (uint32_t)RTW_SAMPLER_ROW : A.sampler;
 }
 
 struct Pixel {            // the work unit a lane owns: a run of consecutive samples of one pixel.  Four registers (they live through every step of
@@ -1252,6 +1253,10 @@ static bool is_demo_config(const KArgs &a) {                   // presentation_i
     return a.integrator == RTW_INTEGRATOR_BG_COLOR && a.sampler == RTW_SAMPLER_ROW && a.depth >= 1 &&
            (a.flags & (RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE)) == 0u;
 }
+static bool is_serial_config(const KArgs &a) {                 // Viewport::render's: ray_color_gradient, stratified
+    return a.integrator == RTW_INTEGRATOR_GRADIENT && a.sampler == RTW_SAMPLER_STRATIFIED && a.depth >= 1 &&
+           (a.flags & (RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE)) == 0u;
+}
 static bool is_rust2_config(const KArgs &a) {                  // Rust2's: ray_color through its fixed-centre render_row
     return a.integrator == RTW_INTEGRATOR_RUST2 && a.sampler == RTW_SAMPLER_CENTRES && a.depth >= 1 &&
            (a.flags & (RTW_FLAG_CPP_DIELECTRIC | RTW_FLAG_CPP_DIFFUSE)) == 0u;
@@ -1282,12 +1287,14 @@ static kernel_fn pick_kernel(const KArgs &a, bool moving, uint32_t accel, bool l
         if (is_common_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<2>(moving, accel, nodes);
         if (is_demo_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<4>(moving, accel, nodes);
         if (is_rust2_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<5>(moving, accel, nodes);
+        if (is_serial_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_geom<6>(moving, accel, nodes);
 #endif
         return pick_kernel_geom<0>(moving, accel, nodes);
     }
 #ifndef RTW_GEOM_GENERIC_ONLY
     if (is_demo_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_spec<4>(moving, accel, nodes);    // (the generic build's step, switches folded in)
     if (is_rust2_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_spec<5>(moving, accel, nodes);
+    if (is_serial_config(a) && !(a.flags & RTW_FLAG_CHUNK_SUMS)) return pick_kernel_spec<6>(moving, accel, nodes);
 #endif
     if (!is_common_config(a)) return pick_kernel_spec<0>(moving, accel, nodes);
     if (a.flags & RTW_FLAG_CHUNK_SUMS) return a.has_textures ? pick_kernel_spec<0>(moving, accel, nodes) : pick_kernel_spec<3>(moving, accel, nodes);
