@@ -1,4 +1,4 @@
-"""The end of a launch, consolidated (RTW_OPT_BAIL_LANES): kernel time of the bench frame, of an eighth of it (one rank's share of N = 8) and of C2 for
+"""The end of a launch, consolidated (RTW_OPT_HAND_LANES): kernel time of the bench frame, of an eighth of it (one rank's share of N = 8) and of C2 for
 several thresholds, with an md5 of every image (the option must not change a bit).  Library: RTW_HIP_LIB."""
 import os, sys, hashlib
 sys.path.insert(0, os.getcwd())
@@ -16,8 +16,8 @@ def frame(name, scene_id, view_id, shutter, part):
     out = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device="cuda:0")
     line = f"{name:34s}"
     for b in vals:
-        if hasattr(R, "OPT_BAIL_LANES"):
-            try: r.set_option(R.OPT_BAIL_LANES, b)
+        if hasattr(R, "OPT_HAND_LANES"):
+            try: r.set_option(R.OPT_HAND_LANES, b)
             except Exception: pass
         out.zero_()
         r.render(cam, p, out=out.data_ptr())
