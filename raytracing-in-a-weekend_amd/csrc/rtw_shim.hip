@@ -37,6 +37,8 @@ struct rtw_ctx {
     bool has_scene = false;
     bool has_textures = false;
     bool bvh_ok = true;                  // false: the tree is deeper than the device stack (never with build_bvh's invariant; checked anyway)
+    double scene_span = 0.0;             // largest |coordinate| a sphere's centre reaches over [t_begin, t_end]; +inf when a centre, velocity or radius is not a number
+                                         // or a centre / velocity is infinite (rtw_ctx_render: only ordinary scenes go through the tree)
     float t_begin = 0.0f, t_end = 0.0f;  // ray.time range the BVH bounds were expanded for (rtw_ctx_set_scene)
     DevScene sc{};
     float bg[3] = { 0, 0, 0 };
@@ -336,6 +338,26 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
     c->bvh.big_index = (const uint32_t *)c->d_big_index; c->bvh.n_big = (uint32_t)bb.big.size();
     c->bvh.root = bb.root; c->bvh.depth = bb.depth;
     c->bvh_ok = bb.depth <= RTW_BVH_STACK;        // build_bvh guarantees it; a deeper tree would overflow the per-lane LDS stack
+    {   // The tree prunes on the premise that the reference's quadratic is computed in ORDINARY f32 (DESIGN.md "Conservative traversal").  A centre at 1e19 or
+        // beyond (|oc|^2 overflows), or a NaN anywhere, makes its discriminant NaN, and a NaN root passes both range tests of sphere.rs:118-121: such a sphere is
+        // "hit" by every ray that reaches it in list order with nothing accepted before -- an order-dependent answer only the list walk gives.  Record how far the
+        // centres reach; rtw_ctx_render decides with the camera in hand.  (Radii: +-inf and huge ones are fine -- those spheres are tested exactly for every
+        // query, and r^2 = inf gives -inf / +inf roots, no NaN; a NaN radius is not.)
+        double span = 0.0;
+        const double tmax = std::fmax(std::fabs((double)t_begin), std::fabs((double)t_end));
+        for (uint32_t i = 0; i < s->n_spheres; i++) {
+            const RtwSphere &q = s->spheres[i];
+            double reach = 0.0;
+            bool odd = q.radius != q.radius;
+            for (int k = 0; k < 3; k++) {
+                const double a = std::fabs((double)q.center[k]), v = std::fabs((double)q.velocity[k]);
+                if (!(a <= 1.7e308) || !(v <= 1.7e308)) odd = true;                   // NaN or inf (NaN compares false: the negated tests catch it; fmax would drop it)
+                else reach = std::fmax(reach, a + v * tmax);
+            }
+            span = std::fmax(span, odd ? HUGE_VAL : reach);
+        }
+        c->scene_span = span;
+    }
     c->scene_serial++;
     scene_cull_from_bvh(bb, s->spheres, c->cull);
     c->cull.n_other = s->n_quads + s->n_instances;
@@ -444,6 +466,9 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         // ... and that the origin is one: past 2^60 (or NaN) the squares of the quadratic overflow and the same NaN roots appear
         const double O[3] = { cam->origin[0], cam->origin[1], cam->origin[2] }, CU[3] = { cam->u[0], cam->u[1], cam->u[2] }, CV[3] = { cam->v[0], cam->v[1], cam->v[2] };
         if (!(norm(O) + std::fabs((double)cam->lens_radius) * (norm(CU) + norm(CV)) <= 0x1p60)) accel = RTW_ACCEL_BRUTE;
+        // ... and that the scene is one (rtw_ctx_set_scene: scene_span): b = oc . d and a c = (d . d)(oc . oc - r^2) must stay below f32's 3.4e38, so
+        // |d| x (the farthest centre + the camera's distance) is kept below 1e18 (camera rays: `hi` above; scattered rays are unit-scale)
+        if (!(std::fmax(hi, 2.0) * (c->scene_span + norm(O) + 1.0) <= 1e18)) accel = RTW_ACCEL_BRUTE;
         // The tree's bounds cover ray.time in [t_begin, t_end] only (rtw_ctx_set_scene): outside it a moving sphere can leave its box
         if (c->sc.moving) {
             const float ta = cam->time0, tb = cam->time0 + cam->shutter;

@@ -236,3 +236,46 @@ def test_book1_with_quads_and_a_medium_through_the_tree(gpu, integrator):
         img, st = gpu.render(cam, q)
         assert st.segments == st_ref.segments and st.quad_tests == st_ref.quad_tests, accel
         assert np.array_equal(img, ref, equal_nan=True), accel
+
+
+@pytest.mark.parametrize("case", ["far 1e17", "far 4e17", "far 6e17", "far 1e19", "far 1e30", "centre -1e25", "centre inf", "centre nan", "radius nan", "radius inf",
+                                  "radius 1e20", "radius 0", "radius negative", "far 1e17 radius 1e17", "velocity nan"])
+def test_spheres_at_extreme_or_non_finite_coordinates(gpu, case):
+    """The reference's quadratic degenerates for a sphere whose centre is at 1e19 or beyond, or not a number: |oc|^2 overflows, the discriminant is NaN,
+    and a NaN root passes both range tests of sphere.rs:118-121 -- such a sphere is hit by every ray that reaches it in list order with nothing accepted
+    before, and real hits never replace it.  Only the list walk gives that order-dependent answer, so a BVH request on such a scene walks the list (the
+    shim bounds |d| x the farthest centre by 1e18; up to round 3 the tree pruned the sphere and rendered another image).  Scenes just below the bound go
+    through the tree and must match too; huge and infinite radii are fine either way (exact test for every query, no NaN).  With the odd sphere first, in the
+    middle and last in list order."""
+    inf, nan = float("inf"), float("nan")
+    odd = {"far 1e17": ((1e17, 0, -8), 1.0), "far 4e17": ((4e17, 3e17, -8), 1.0), "far 6e17": ((6e17, 0, -8), 1.0), "far 1e19": ((1e19, 0, -8), 1.0),
+           "far 1e30": ((1e30, 0, -8), 1.0), "centre -1e25": ((0, 0, 1e25), 3.0), "centre inf": ((inf, 0, -8), 1.0), "centre nan": ((nan, 0, -8), 1.0),
+           "radius nan": ((0, 1, -8), nan), "radius inf": ((0, 1, -8), inf), "radius 1e20": ((0, 0, -8), 1e20), "radius 0": ((0, 1, -6), 0.0),
+           "radius negative": ((0.5, 0.5, -6), -0.7), "far 1e17 radius 1e17": ((1e17, 0, -8), 1e17), "velocity nan": ((0, 1, -6), 0.5)}[case]
+    rng = np.random.default_rng(5)
+    mats = [R.SCATTER_M, R.METALLIC_M, R.GLASS_M]
+    vp = R.Viewport.new_from_res(96, 54, 4, 8, 1.0, vfov=70.0, lens_radius=0.0)
+    cam = vp.camera(); p = vp.params(R.INTEGRATOR_GRADIENT, R.SAMPLER_ROW)
+    for pos in (0, 30, 60):
+        sp = [R.Sphere.with_albedo(rng.uniform(-4, 4, 3) + [0, 0, -8], float(rng.uniform(0.2, 0.6)), rng.uniform(0.2, 0.95, 3), mats[i % 3]) for i in range(60)]
+        vel = (nan, 0.0, 0.0) if case == "velocity nan" else (0.0, 0.0, 0.0)
+        extra = R.Sphere.with_albedo(odd[0], odd[1], (0.9, 0.2, 0.2), R.SCATTER_M, velocity=vel)
+        sp.insert(pos, extra)
+        scene = R.Scene(sp)
+        ref, st_ref, out = render_both_r3(gpu, scene, cam, p)
+        for accel, (img, st) in out.items():
+            assert st.segments == st_ref.segments, (case, pos, accel)
+            assert np.array_equal(img, ref, equal_nan=True), (case, pos, accel)
+
+
+def render_both_r3(gpu, scene, cam, p):
+    ref, st_ref = O.render(cam, scene, p, 16)
+    gpu.set_scene(scene, cam.time0, cam.time0 + cam.shutter)
+    out = {}
+    try:
+        for name, walk_max, accel in (("list walk", 48, R.ACCEL_BRUTE), ("bvh request", 48, R.ACCEL_BVH), ("tree forced", 0, R.ACCEL_BVH)):
+            gpu.set_option(R.OPT_LIST_WALK_MAX, walk_max); p.accel = accel
+            out[name] = gpu.render(cam, p)
+    finally:
+        gpu.set_option(R.OPT_LIST_WALK_MAX, 48)
+    return ref, st_ref, out
