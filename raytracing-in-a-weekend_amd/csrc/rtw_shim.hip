@@ -349,6 +349,13 @@ int rtw_ctx_set_scene(rtw_ctx *c, const RtwScene *s, float t_begin, float t_end)
             const RtwSphere &q = s->spheres[i];
             double reach = 0.0;
             bool odd = q.radius != q.radius;
+            // ... and a material that can turn a ray into one: the scattered direction is reflect * m + scatter * (1 - m), or a refraction with ratio ir or 1 / ir
+            // (materials.rs:105-154) -- finite and of ordinary size exactly when m and ir are (a NaN or 1e30 there makes the NEXT ray NaN or |d|^2 overflow)
+            {
+                const double m = std::fabs((double)q.metallicness), ir = std::fabs((double)q.ir);
+                if (!(m <= 1e10)) odd = true;
+                if (q.opacity > 0.0f && !(ir >= 1e-10 && ir <= 1e10)) odd = true;         // (ir is read by the dielectric branch only)
+            }
             for (int k = 0; k < 3; k++) {
                 const double a = std::fabs((double)q.center[k]), v = std::fabs((double)q.velocity[k]);
                 if (!(a <= 1.7e308) || !(v <= 1.7e308)) odd = true;                   // NaN or inf (NaN compares false: the negated tests catch it; fmax would drop it)
@@ -469,6 +476,8 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         // ... and that the scene is one (rtw_ctx_set_scene: scene_span): b = oc . d and a c = (d . d)(oc . oc - r^2) must stay below f32's 3.4e38, so
         // |d| x (the farthest centre + the camera's distance) is kept below 1e18 (camera rays: `hi` above; scattered rays are unit-scale)
         if (!(std::fmax(hi, 2.0) * (c->scene_span + norm(O) + 1.0) <= 1e18)) accel = RTW_ACCEL_BRUTE;
+        // ... and the accepted range: with a NaN bound the reference's `x < mint || x > maxt` rejects nothing, where the tree's interval test rejects everything
+        if (p->mint != p->mint || p->maxt != p->maxt) accel = RTW_ACCEL_BRUTE;
         // The tree's bounds cover ray.time in [t_begin, t_end] only (rtw_ctx_set_scene): outside it a moving sphere can leave its box
         if (c->sc.moving) {
             const float ta = cam->time0, tb = cam->time0 + cam->shutter;

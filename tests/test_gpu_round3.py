@@ -279,3 +279,35 @@ def render_both_r3(gpu, scene, cam, p):
     finally:
         gpu.set_option(R.OPT_LIST_WALK_MAX, 48)
     return ref, st_ref, out
+
+
+@pytest.mark.parametrize("case", ["maxt nan", "maxt inf", "mint nan", "mint inf", "mint -1", "ir nan", "ir 0", "ir inf", "ir 1e30", "ir -1.5", "metallicness nan", "metallicness inf",
+                                  "metallicness 1e30", "metallicness 2", "metallicness -1", "opacity nan", "albedo nan", "albedo inf", "depth 200"])
+def test_odd_ranges_and_material_scalars(gpu, case):
+    """More inputs that take the reference's arithmetic out of the ordinary.  A NaN `maxt` makes `x > maxt` reject nothing; a NaN (or absurd) metallicness or
+    refraction index makes the NEXT ray NaN or its |d|^2 overflow, and such a ray "hits" the first sphere of the list (NaN roots pass, sphere.rs:118-121).  A BVH
+    request on such inputs walks the list (rtw_ctx_set_scene / rtw_ctx_render record and test it); everything else here goes through the tree.  Found with
+    scripts/gpu_extreme2.py (profiles/r03_extreme3.log: the tree rendered maxt = NaN, ir = NaN and metallicness = NaN differently up to round 3)."""
+    inf, nan = float("inf"), float("nan")
+    rng = np.random.default_rng(7)
+    mats = [R.SCATTER_M, R.METALLIC_M, R.GLASS_M, R.FUZZY3_M]
+    sp = [R.Sphere.with_albedo((0, -100.5, -8), 100.0, (0.5, 0.5, 0.5), R.SCATTER_M)]
+    sp += [R.Sphere.with_albedo(rng.uniform(-4, 4, 3) + [0, 0, -8], float(rng.uniform(0.2, 0.6)), rng.uniform(0.2, 0.95, 3), mats[i % 4]) for i in range(70)]
+    odd = {"ir nan": ((1.0, 1.0, nan), (1, 1, 1)), "ir 0": ((1.0, 1.0, 0.0), (1, 1, 1)), "ir inf": ((1.0, 1.0, inf), (1, 1, 1)), "ir 1e30": ((1.0, 1.0, 1e30), (1, 1, 1)),
+           "ir -1.5": ((1.0, 1.0, -1.5), (1, 1, 1)), "metallicness nan": ((nan, 0.0, 1.0), (0.8, 0.8, 0.8)), "metallicness inf": ((inf, 0.0, 1.0), (0.8, 0.8, 0.8)),
+           "metallicness 1e30": ((1e30, 0.0, 1.0), (0.8, 0.8, 0.8)), "metallicness 2": ((2.0, 0.0, 1.0), (0.8, 0.8, 0.8)), "metallicness -1": ((-1.0, 0.0, 1.0), (0.8, 0.8, 0.8)),
+           "opacity nan": ((0.5, nan, 1.5), (0.8, 0.8, 0.8)), "albedo nan": (R.SCATTER_M, (nan, 0.5, 0.5)), "albedo inf": (R.SCATTER_M, (inf, 0.5, 0.5))}.get(case)
+    if odd is not None:
+        for i in range(1, 70, 3): sp[i] = R.Sphere.with_albedo(tuple(sp[i].pod.center), sp[i].pod.radius, odd[1], odd[0])
+    vp = R.Viewport.new_from_res(96, 54, 4, 12, 1.0, vfov=70.0, lens_radius=0.02)
+    cam = vp.camera(); p = vp.params(R.INTEGRATOR_GRADIENT, R.SAMPLER_ROW)
+    if case == "maxt nan": p.maxt = nan
+    if case == "maxt inf": p.maxt = inf
+    if case == "mint nan": p.mint = nan
+    if case == "mint inf": p.mint = inf
+    if case == "mint -1": p.mint = -1.0
+    if case == "depth 200": p.depth = 200
+    ref, st_ref, out = render_both_r3(gpu, R.Scene(sp), cam, p)
+    for accel, (img, st) in out.items():
+        assert st.segments == st_ref.segments, (case, accel)
+        assert np.array_equal(img, ref, equal_nan=True), (case, accel)
