@@ -311,3 +311,28 @@ def test_odd_ranges_and_material_scalars(gpu, case):
     for accel, (img, st) in out.items():
         assert st.segments == st_ref.segments, (case, accel)
         assert np.array_equal(img, ref, equal_nan=True), (case, accel)
+
+
+def test_two_hundred_thousand_spheres_tree_equals_list(gpu):
+    """A scene far beyond the reference's sizes (200 000 spheres: nodes in global memory, a tree ~18 levels deep): the traversal kernel returns the list walk's
+    image bit for bit (no oracle here: the CPU would need minutes).  scripts/gpu_many_spheres.py goes to a million."""
+    n = 200000
+    rng = np.random.default_rng(n)
+    pods = (R.RtwSphere * n)()
+    base = R.Sphere.with_albedo((0, 0, 0), 1.0, (0.7, 0.6, 0.5), R.SCATTER_M).pod
+    np.frombuffer(pods, dtype=np.uint8).reshape(n, -1)[:] = np.frombuffer(bytes(base), dtype=np.uint8)
+    f = np.frombuffer(pods, dtype=np.float32).reshape(n, -1)
+    f[:, 0:3] = rng.uniform(-30, 30, (n, 3)).astype(np.float32) + np.float32([0, 0, -40])
+    f[:, 3] = rng.uniform(0.02, 0.25, n).astype(np.float32)
+    scene = R.Scene([R.Sphere.with_albedo((0, 0, 0), 1.0, (0.7, 0.6, 0.5), R.SCATTER_M)])
+    scene._spheres = pods; scene.n_spheres = n                    # (the ctypes array stands in for the list of wrappers: 200 000 Python objects are slow)
+    scene.pod.spheres = pods; scene.pod.n_spheres = n
+    vp = R.Viewport.new_from_res(96, 54, 2, 8, 1.0, vfov=70.0, lens_radius=0.01)
+    cam = vp.camera(); p = vp.params(R.INTEGRATOR_GRADIENT, R.SAMPLER_ROW)
+    gpu.set_scene(scene)
+    p.accel = R.ACCEL_BVH
+    a, sa = gpu.render(cam, p)
+    p.accel = R.ACCEL_BRUTE
+    b, sb = gpu.render(cam, p)
+    assert sa.node_tests > 0 and sb.node_tests == 0
+    assert sa.segments == sb.segments and np.array_equal(a, b, equal_nan=True)
