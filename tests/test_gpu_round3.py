@@ -336,3 +336,37 @@ def test_two_hundred_thousand_spheres_tree_equals_list(gpu):
     b, sb = gpu.render(cam, p)
     assert sa.node_tests > 0 and sb.node_tests == 0
     assert sa.segments == sb.segments and np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("integrator", ["gradient", "bg_color"])
+def test_odd_quads_instances_and_media_next_to_a_field_of_spheres(gpu, integrator):
+    """Degenerate and non-finite quads, instances rotated by NaN or moved to infinity, smokes of density 0 / negative / NaN / inf / 1e-30 / 1e30, each next to 70
+    spheres that go through the tree: the GEOM builds (which test every new ray and walk the list for one that is not finite) and the list walk render the oracle's
+    image.  scripts/gpu_extreme3.py; profiles/r03_extreme4.log."""
+    inf, nan = float("inf"), float("nan")
+    rng = np.random.default_rng(9)
+    mats = [R.SCATTER_M, R.METALLIC_M, R.GLASS_M]
+    def field():
+        return [R.Sphere.with_albedo(rng.uniform(-4, 4, 3) + [0, 0, -8], float(rng.uniform(0.2, 0.6)), rng.uniform(0.2, 0.95, 3), mats[i % 3]) for i in range(70)]
+    def box(rot=(0.0, 0.5, 0.0), tr=(1.5, 0.0, -6.0), density=None):
+        b = R.Instance.new_box((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), (0.8, 0.8, 0.8), R.SCATTER_M)
+        b.rotate(rot); b.translate(tr)
+        if density is not None: b.const_density(density)
+        return b
+    bg = (0.4, 0.5, 0.7)
+    scenes = [R.Scene(field(), background=bg, quads=[R.Quad.new((-3, -1, -9), (6, 0, 0), (3, 0, 0), R.SCATTER_M, (0.8, 0.8, 0.8))]),            # u x v = 0
+              R.Scene(field(), background=bg, quads=[R.Quad.new((nan, -1, -9), (6, 0, 0), (0, 4, 0), R.SCATTER_M, (0.8, 0.8, 0.8))]),
+              R.Scene(field(), background=bg, quads=[R.Quad.new((1e20, -1, -9), (6, 0, 0), (0, 4, 0), R.SCATTER_M, (0.8, 0.8, 0.8))]),
+              R.Scene(field(), background=bg, quads=[R.Quad.new((-5e19, -5e19, -12), (1e20, 0, 0), (0, 1e20, 0), R.SCATTER_M, (0.8, 0.8, 0.8))]),
+              R.Scene(field(), background=bg, instances=[box(rot=(0.0, nan, 0.0))]),
+              R.Scene(field(), background=bg, instances=[box(tr=(inf, 0.0, -6.0))]),
+              R.Scene(field(), background=bg, instances=[box(tr=(1e25, 0.0, -6.0))])]
+    scenes += [R.Scene(field(), background=bg, instances=[box(density=d)]) for d in (0.0, -1.0, nan, inf, 1e-30, 1e30)]
+    vp = R.Viewport.new_from_res(96, 54, 4, 10, 1.0, vfov=70.0, lens_radius=0.0)
+    cam = vp.camera()
+    p = vp.params(R.INTEGRATOR_GRADIENT if integrator == "gradient" else R.INTEGRATOR_BG_COLOR, R.SAMPLER_ROW)
+    for k, scene in enumerate(scenes):
+        ref, st_ref, out = render_both_r3(gpu, scene, cam, p)
+        for accel, (img, st) in out.items():
+            assert st.segments == st_ref.segments, (k, accel)
+            assert np.array_equal(img, ref, equal_nan=True), (k, accel)
