@@ -482,6 +482,7 @@ static int render_enqueue_impl(rtw_ctx *c, const RtwCamera *cam, const RtwParams
         if (c->sc.moving) {
             const float ta = cam->time0, tb = cam->time0 + cam->shutter;
             if (!(std::fmin(ta, tb) >= c->t_begin && std::fmax(ta, tb) <= c->t_end)) accel = RTW_ACCEL_BRUTE;
+            if (ta != ta || tb != tb) accel = RTW_ACCEL_BRUTE;         // (fmin / fmax drop a NaN: a NaN shutter makes every moving centre NaN, which only the list walk answers like the reference)
         }
         if (!c->bvh_ok) accel = RTW_ACCEL_BRUTE;
         // a handful of spheres: the list walk IS the fastest closest-hit (the traversal scheduler only costs)

@@ -370,3 +370,23 @@ def test_odd_quads_instances_and_media_next_to_a_field_of_spheres(gpu, integrato
         for accel, (img, st) in out.items():
             assert st.segments == st_ref.segments, (k, accel)
             assert np.array_equal(img, ref, equal_nan=True), (k, accel)
+
+
+@pytest.mark.parametrize("case", ["shutter nan", "time0 nan", "time0 inf", "shutter negative", "shutter 1e30", "time0 -1e10"])
+def test_odd_times_with_moving_spheres(gpu, case):
+    """Ray times out of the ordinary with a third of the spheres moving: a NaN shutter makes every moving centre NaN (centre = origin + velocity * time,
+    sphere.rs:100) and with it the reference's NaN-root hits; up to round 3 a NaN slipped through the shim's fmin / fmax range check and the tree
+    rendered another image.  scripts/gpu_extreme4.py, profiles/r03_extreme5.log."""
+    inf, nan = float("inf"), float("nan")
+    t0, sh = {"shutter nan": (0.0, nan), "time0 nan": (nan, 0.02), "time0 inf": (inf, 0.0), "shutter negative": (0.5, -0.03), "shutter 1e30": (0.0, 1e30), "time0 -1e10": (-1e10, 0.0)}[case]
+    rng = np.random.default_rng(11)
+    mats = [R.SCATTER_M, R.METALLIC_M, R.GLASS_M]
+    sp = [R.Sphere.with_albedo(rng.uniform(-4, 4, 3) + [0, 0, -8], float(rng.uniform(0.2, 0.6)), rng.uniform(0.2, 0.95, 3), mats[i % 3],
+                               velocity=tuple(rng.uniform(-3, 3, 3)) if i % 3 == 0 else (0, 0, 0)) for i in range(70)]
+    vp = R.Viewport.new_from_res(96, 54, 4, 10, 1.0, vfov=70.0, lens_radius=0.01)
+    cam = vp.camera(); cam.time0, cam.shutter = t0, sh
+    p = vp.params(R.INTEGRATOR_GRADIENT, R.SAMPLER_ROW)
+    ref, st_ref, out = render_both_r3(gpu, R.Scene(sp), cam, p)
+    for accel, (img, st) in out.items():
+        assert st.segments == st_ref.segments, (case, accel)
+        assert np.array_equal(img, ref, equal_nan=True), (case, accel)
